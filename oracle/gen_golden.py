@@ -1,0 +1,178 @@
+"""Generate the golden vectors that pin ``oracle/maskcbam_oracle.py`` (and through it the HIP kernels).
+
+TEST INFRASTRUCTURE.  Run ONCE in the build container, where the upstream reference is mounted read-only:
+
+    PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference python oracle/gen_golden.py
+
+It imports the reference's own ``mga_yolo.nn.modules.masked_cbam.MaskCBAM`` (torch-only, imports cleanly
+here -- SURVEY.md section 8c), runs forward + backward on seeded inputs and writes
+
+* ``tests/golden/case_*.npz``      -- inputs, parameters, y and every gradient for small shapes
+* ``tests/golden/checksums.json``  -- float64 checksums of y / gradients for full-size shapes
+                                      (BASELINE.json configs 1 and 2) that are too large to commit
+
+Only data is written -- no reference source text.  The reference never travels to the GPU box.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+from mga_yolo.nn.modules.masked_cbam import MaskCBAM  # the reference itself
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+torch.set_num_threads(1)  # deterministic summation order
+
+
+def build(C, r=16, k=7, use_sigmoid_mask=True, seed=0, randomize=None, beta=None):
+    torch.manual_seed(seed)
+    m = MaskCBAM(C, r=r, spatial_k=k, use_sigmoid_mask=use_sigmoid_mask)
+    if randomize is not None:  # "trained-like" parameters: every entry perturbed
+        g = torch.Generator().manual_seed(randomize)
+        with torch.no_grad():
+            for p_ in m.parameters():
+                p_.add_(0.5 * torch.randn(p_.shape, generator=g))
+    if beta is not None:
+        with torch.no_grad():
+            m.beta.fill_(beta)
+    return m
+
+
+def run(m, x, mask, gy):
+    x = x.clone().requires_grad_(True)
+    mk = None if mask is None else mask.clone().requires_grad_(True)
+    m.zero_grad()
+    y = m(x if mk is None else [x, mk])
+    y.backward(gy)
+    out = dict(y=y.detach(), gx=x.grad)
+    if mk is not None:
+        out["gmask"] = mk.grad
+    sd = m.state_dict()
+    names = {"gw1": "cam_mlp.0.weight", "gb1": "cam_mlp.0.bias", "gw2": "cam_mlp.2.weight",
+             "gb2": "cam_mlp.2.bias", "gwsa": "sam_conv.weight", "gbeta": "beta"}
+    params = dict(m.named_parameters())
+    for g_, n_ in names.items():
+        out[g_] = params[n_].grad.detach().clone()
+    return out, {k_: v.detach().clone() for k_, v in sd.items()}
+
+
+def data(B, C, H, W, seed=1234, mask_kind="randn", mask3d=False, x_kind="randn"):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, H, W, generator=g)
+    if x_kind == "quantized":      # many exact ties, for first-index tie-breaking
+        x = torch.round(x * 2.0) / 2.0
+    elif x_kind == "relu":
+        x = torch.relu(x)
+    elif x_kind == "zeros":
+        x = torch.zeros(B, C, H, W)
+    ms = (B, H, W) if mask3d else (B, 1, H, W)
+    r = torch.randn(ms, generator=g)
+    if mask_kind == "randn":
+        mask = r
+    elif mask_kind == "none":
+        mask = None
+    elif mask_kind == "all_negative":     # nothing selected -> masked max falls back to GAP
+        mask = -r.abs() - 0.1
+    elif mask_kind == "tiny":             # sigmoid(-20) ~ 2e-9 -> use_mask = 0 -> masked avg falls back to GAP
+        mask = torch.full(ms, -20.0)
+    elif mask_kind == "sparse":           # vessel-like coverage
+        mask = r - 2.0
+    elif mask_kind == "prob":             # use_sigmoid_mask=False: mask already a probability
+        mask = torch.rand(ms, generator=g)
+    elif mask_kind == "zeros":
+        mask = torch.zeros(ms)
+    elif mask_kind == "mixed":            # per-sample branches: normal / nothing selected / tiny
+        mask = r.clone()
+        mask[1] = -mask[1].abs() - 0.1
+        if B > 2:
+            mask[2] = -20.0
+    else:
+        raise ValueError(mask_kind)
+    gy = torch.randn(B, C, H, W, generator=g)
+    return x, mask, gy
+
+
+CASES = [
+    # name,            B,  C,  H,  W, module kwargs,                         data kwargs
+    ("base",           2, 64, 20, 20, dict(),                                 dict()),
+    ("nomask",         2, 32, 12, 12, dict(),                                 dict(mask_kind="none")),
+    ("all_negative",   2, 16, 10, 10, dict(),                                 dict(mask_kind="all_negative")),
+    ("tiny_mask",      2, 16, 10, 10, dict(),                                 dict(mask_kind="tiny")),
+    ("mask3d",         1, 16,  8,  8, dict(),                                 dict(mask3d=True)),
+    ("hidden1_nonsq",  2,  8,  9,  7, dict(),                                 dict()),
+    ("odd17_c48",      1, 48, 17, 17, dict(),                                 dict()),
+    ("c192",           1, 192, 8,  8, dict(),                                 dict()),
+    ("ties",           2, 16,  8,  8, dict(randomize=7),                      dict(x_kind="quantized")),
+    ("relu_sparse",    2, 32, 12, 16, dict(randomize=3),                      dict(x_kind="relu", mask_kind="sparse")),
+    ("prob_mask",      2, 16,  8,  8, dict(use_sigmoid_mask=False),           dict(mask_kind="prob")),
+    ("mixed_batch",    3, 32, 10, 10, dict(randomize=11),                     dict(mask_kind="mixed")),
+    ("k3",             1, 16,  8,  8, dict(k=3, randomize=5),                 dict()),
+    ("k5",             1, 16,  8,  8, dict(k=5, randomize=5),                 dict()),
+    ("r4",             2, 32,  8,  8, dict(r=4, randomize=9),                 dict()),
+    ("beta_pos",       2, 32,  8,  8, dict(randomize=13, beta=0.7),           dict()),
+    ("beta_neg",       2, 32,  8,  8, dict(randomize=13, beta=-1.3),          dict()),
+    ("stride_probe",   1, 64, 32, 32, dict(),                                 dict(x_kind="zeros", mask_kind="zeros")),
+    ("p5_like",        2, 256, 5,  5, dict(randomize=17),                     dict()),
+    ("w1_tail",        2, 16,  6, 10, dict(randomize=19),                     dict(mask_kind="sparse")),
+]
+
+# full-size shapes: only checksums are kept (x is 3-52 MB)
+BIG = [
+    # name,                 B,  C,  H,  W, mask_kind, recipe
+    ("survey_A1",           2, 64, 80, 80, "randn", "ysum"),       # SURVEY.md appendix A1 / section 8c case (1)
+    ("survey_nomask",       2, 64, 80, 80, "none", "ysum"),        # case (2)
+    ("cfg1_p3",             2, 64, 80, 80, "randn", "gy"),
+    ("cfg1_p4",             2, 128, 40, 40, "randn", "gy"),
+    ("cfg1_p5",             2, 256, 20, 20, "randn", "gy"),
+    ("cfg2_p3",            32, 64, 80, 80, "sparse", "gy"),
+    ("cfg2_p4",            32, 128, 40, 40, "sparse", "gy"),
+    ("cfg2_p5",            32, 256, 20, 20, "sparse", "gy"),
+]
+
+
+def checksum(tn):
+    t = tn.double().reshape(-1)
+    n = t.numel()
+    w = torch.cos(torch.arange(n, dtype=torch.float64) * 0.37)   # position-sensitive weight
+    return dict(sum=float(t.sum()), abs=float(t.abs().sum()), wsum=float((t * w).sum()), n=n,
+                first=float(t[0]), last=float(t[-1]))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    index = {}
+    for name, B, C, H, W, mk, dk in CASES:
+        m = build(C, **mk)
+        x, mask, gy = data(B, C, H, W, **dk)
+        out, sd = run(m, x, mask, gy)
+        arrays = dict(x=x.numpy(), gy=gy.numpy())
+        if mask is not None:
+            arrays["mask"] = mask.numpy()
+        for k_, v in sd.items():
+            arrays["param." + k_] = v.numpy()
+        for k_, v in out.items():
+            arrays["out." + k_] = v.numpy()
+        meta = dict(r=mk.get("r", 16), k=m.k, use_sigmoid_mask=bool(m.use_sigmoid_mask), tiny_thr=m.tiny_thr, eps=m.eps)
+        arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, f"case_{name}.npz"), **arrays)
+        index[name] = dict(shape=[B, C, H, W], **meta, ysum=float(out["y"].double().sum()))
+        print(f"case {name:16s} y.sum={index[name]['ysum']:.6f}")
+
+    sums = {}
+    for name, B, C, H, W, mkind, recipe in BIG:
+        m = build(C)
+        x, mask, gy = data(B, C, H, W, mask_kind=mkind)
+        if recipe == "ysum":
+            gy = torch.ones_like(x)
+        out, _ = run(m, x, mask, gy)
+        sums[name] = dict(shape=[B, C, H, W], mask_kind=mkind, recipe=recipe,
+                          **{k_: checksum(v) for k_, v in out.items()})
+        print(f"big  {name:16s} y.sum={sums[name]['y']['sum']:.6f} |gx|={sums[name]['gx']['abs']:.6f}")
+    with open(os.path.join(OUT, "checksums.json"), "w") as f:
+        json.dump(dict(cases=index, big=sums, torch=torch.__version__), f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    sys.exit(main())
