@@ -1,0 +1,133 @@
+/*
+ * mgacbam.h -- C ABI of the MI355X (gfx950) mask-guided CBAM library (libmgacbam.so).
+ *
+ * This is the drop-in boundary for ONE hot path of MGA-YOLO: the MaskCBAM block, forward and backward
+ * (reference: mga_yolo/nn/modules/masked_cbam.py:10-174).  Nothing like this ABI exists in the
+ * reference -- there the block is ~65 eager ATen ops forward / ~90 backward; the Python mirror of the
+ * reference module (mga_yolo_amd/module.py) binds these entry points with ctypes and keeps the
+ * reference's nn.Module contract (constructor, [feat, mask] list input, state_dict keys, .alpha).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / C++ types.  `stream` is a hipStream_t passed as void*.
+ *   - the caller owns every buffer (features, gradients, ctx, scratch); the library never allocates,
+ *     frees, copies to the host or synchronises, so every call may be captured in a hipGraph.
+ *   - re-entrant: no mutable globals except a thread-local error string.
+ *   - return value: 0 = ok, <0 = argument error (MGACBAM_E_*), >0 = hipError_t from a launch.
+ *   - tensors are dense NCHW; `dtype` selects the element type of x / y / gy / gx (mask, parameters,
+ *     every accumulator and every saved statistic are fp32).
+ */
+#ifndef MGACBAM_H_
+#define MGACBAM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGACBAM_ABI_VERSION 1
+#define MGACBAM_MAX_LEVELS 8          /* P3/P4/P5 need 3 */
+
+enum { MGACBAM_F32 = 0, MGACBAM_F16 = 1, MGACBAM_BF16 = 2 };
+
+enum {
+  MGACBAM_E_NULL = -1,        /* required pointer is NULL */
+  MGACBAM_E_SHAPE = -2,       /* B,C,H,W,hidden,k out of range */
+  MGACBAM_E_DTYPE = -3,
+  MGACBAM_E_ALIGN = -4,       /* ctx/scratch not 16-byte aligned */
+  MGACBAM_E_LEVELS = -5       /* n_levels outside 1..MGACBAM_MAX_LEVELS */
+};
+
+/* Constructor arguments + learnable state of one block (reference masked_cbam.py:34-64).
+ * Parameter tensors are the reference's state_dict entries, fp32, contiguous, on the device:
+ *   w1  = cam_mlp.0.weight (hidden, C)     b1 = cam_mlp.0.bias (hidden)
+ *   w2  = cam_mlp.2.weight (C, hidden)     b2 = cam_mlp.2.bias (C)
+ *   wsa = sam_conv.weight  (1, 3, k, k)    beta = beta ()        -- alpha = softplus(beta) is formed on
+ * the device so that no host read of a parameter (a sync) is ever needed. */
+typedef struct mgacbam_params {
+  const float* w1;
+  const float* b1;
+  const float* w2;
+  const float* b2;
+  const float* wsa;
+  const float* beta;
+  int32_t hidden;            /* max(1, C / r) */
+  int32_t k;                 /* odd spatial kernel size, 1..15 */
+  int32_t use_sigmoid_mask;  /* masked_cbam.py:39 */
+  float tiny_thr;            /* masked_cbam.py:40 */
+  float eps;                 /* masked_cbam.py:41 */
+} mgacbam_params_t;
+
+/* One pyramid level of a forward call: replaces MaskCBAM.forward([feat, mask]) (masked_cbam.py:154-171). */
+typedef struct mgacbam_fwd_level {
+  const void* x;             /* (B,C,H,W) feature                              */
+  const float* mask;         /* (B,1,H,W) fp32 logits, or NULL = vanilla CBAM  */
+  void* y;                   /* (B,C,H,W) output, same dtype as x              */
+  void* ctx;                 /* mgacbam_ctx_bytes(): statistics saved for backward (or inspection) */
+  mgacbam_params_t p;
+  int32_t B, C, H, W;
+  int32_t dtype;
+} mgacbam_fwd_level_t;
+
+/* One pyramid level of a backward call: replaces what autograd derives for the block. */
+typedef struct mgacbam_bwd_level {
+  const void* x;             /* as in forward                                   */
+  const float* mask;         /* as in forward (NULL if it was NULL)             */
+  const void* gy;            /* (B,C,H,W) dL/dy                                 */
+  const void* ctx;           /* written by the matching forward                 */
+  void* scratch;             /* mgacbam_bwd_scratch_bytes(), contents undefined */
+  void* gx;                  /* (B,C,H,W) dL/dx                                 */
+  float* gmask;              /* (B,1,H,W) dL/dmask, or NULL if not wanted       */
+  float* gw1;                /* parameter gradients, same shapes as parameters; OVERWRITTEN (not accumulated) */
+  float* gb1;
+  float* gw2;
+  float* gb2;
+  float* gwsa;
+  float* gbeta;
+  mgacbam_params_t p;
+  int32_t B, C, H, W;
+  int32_t dtype;
+} mgacbam_bwd_level_t;
+
+/* Named regions inside ctx (byte offsets), for stage-wise tests and tooling.  All fp32 unless noted. */
+typedef struct mgacbam_ctx_layout {
+  int64_t S;        /* (B)      sum_hw sigma(mask)                        masked_cbam.py:99  */
+  int64_t use;      /* (B)      1.0 if mean sigma(mask) >= tiny_thr       masked_cbam.py:98  */
+  int64_t den;      /* (B)      max(S, eps)                               masked_cbam.py:99  */
+  int64_t avg;      /* (B,C)    pooled descriptor fed to the MLP          masked_cbam.py:102 */
+  int64_t mx;       /* (B,C)    pooled descriptor fed to the MLP          masked_cbam.py:121 */
+  int64_t mavg;     /* (B,C)    masked average before the GAP blend       masked_cbam.py:100 */
+  int64_t valid;    /* (B,C)    int32: 1 = masked max used, 0 = GAP fallback   masked_cbam.py:120 */
+  int64_t amax;     /* (B,C)    int32: first arg-max position in H*W           masked_cbam.py:117 */
+  int64_t h_avg;    /* (B,hid)  relu(W1 avg + b1)                          masked_cbam.py:54-56 */
+  int64_t h_mx;     /* (B,hid)  relu(W1 mx + b1)                                              */
+  int64_t ca;       /* (B,C)    channel gate                              masked_cbam.py:129 */
+  int64_t planes;   /* (B,3,HW) [max_c u, mean_c u, sigma(mask)]           masked_cbam.py:146 */
+  int64_t cidx;     /* (B,HW)   int32: first arg-max channel of u          masked_cbam.py:135 */
+  int64_t sa;       /* (B,HW)   spatial gate                              masked_cbam.py:147 */
+  int64_t total;    /* == mgacbam_ctx_bytes()                                                 */
+} mgacbam_ctx_layout_t;
+
+int mgacbam_abi_version(void);
+const char* mgacbam_last_error(void);      /* thread-local, valid until the next call on this thread */
+const char* mgacbam_build_info(void);      /* "gfx950 hipcc-x.y ..." */
+
+size_t mgacbam_ctx_bytes(int B, int C, int H, int W, int hidden);
+size_t mgacbam_bwd_scratch_bytes(int B, int C, int H, int W, int hidden, int k);
+int mgacbam_ctx_layout(int B, int C, int H, int W, int hidden, mgacbam_ctx_layout_t* out);
+
+/* Forward / backward over n_levels independent pyramid levels (P3/P4/P5 = 3) enqueued on `stream`. */
+int mgacbam_forward(const mgacbam_fwd_level_t* levels, int n_levels, void* stream);
+int mgacbam_backward(const mgacbam_bwd_level_t* levels, int n_levels, void* stream);
+
+/* Nearest-neighbour resize of (n_planes, in_h, in_w) fp32 planes to (n_planes, out_h, out_w): the integer
+ * index path src = min(floor(dst * in/out), in-1) of mga_yolo/nn/losses/segmentation.py:103-110
+ * (F.interpolate(mode="nearest")).  Bit-exact with the reference by construction (pure gather). */
+int mgacbam_resize_nearest(const float* src, float* dst, int n_planes, int in_h, int in_w, int out_h, int out_w,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGACBAM_H_ */

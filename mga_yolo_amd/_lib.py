@@ -1,0 +1,123 @@
+"""ctypes binding of libmgacbam.so (C ABI: include/mgacbam.h).  There is NO fallback: if the library is missing
+or an entry point is absent, loading raises -- device tensors never take another path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmgacbam.so")
+ABI_VERSION = 1
+MAX_LEVELS = 8
+F32, F16, BF16 = 0, 1, 2
+
+_c_float_p = C.POINTER(C.c_float)
+
+
+class Params(C.Structure):                       # mgacbam_params_t
+    _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("wsa", C.c_void_p), ("beta", C.c_void_p),
+                ("hidden", C.c_int32), ("k", C.c_int32), ("use_sigmoid_mask", C.c_int32),
+                ("tiny_thr", C.c_float), ("eps", C.c_float)]
+
+
+class FwdLevel(C.Structure):                     # mgacbam_fwd_level_t
+    _fields_ = [("x", C.c_void_p), ("mask", C.c_void_p), ("y", C.c_void_p), ("ctx", C.c_void_p),
+                ("p", Params), ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("dtype", C.c_int32)]
+
+
+class BwdLevel(C.Structure):                     # mgacbam_bwd_level_t
+    _fields_ = [("x", C.c_void_p), ("mask", C.c_void_p), ("gy", C.c_void_p), ("ctx", C.c_void_p),
+                ("scratch", C.c_void_p), ("gx", C.c_void_p), ("gmask", C.c_void_p),
+                ("gw1", C.c_void_p), ("gb1", C.c_void_p), ("gw2", C.c_void_p), ("gb2", C.c_void_p),
+                ("gwsa", C.c_void_p), ("gbeta", C.c_void_p),
+                ("p", Params), ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("dtype", C.c_int32)]
+
+
+CTX_FIELDS = ("S", "use", "den", "avg", "mx", "mavg", "valid", "amax", "h_avg", "h_mx", "ca", "planes", "cidx", "sa", "total")
+
+
+class CtxLayout(C.Structure):                    # mgacbam_ctx_layout_t
+    _fields_ = [(n, C.c_int64) for n in CTX_FIELDS]
+
+
+# every symbol include/mgacbam.h declares: (restype, argtypes)
+SYMBOLS = {
+    "mgacbam_abi_version": (C.c_int, []),
+    "mgacbam_last_error": (C.c_char_p, []),
+    "mgacbam_build_info": (C.c_char_p, []),
+    "mgacbam_ctx_bytes": (C.c_size_t, [C.c_int] * 5),
+    "mgacbam_bwd_scratch_bytes": (C.c_size_t, [C.c_int] * 6),
+    "mgacbam_ctx_layout": (C.c_int, [C.c_int] * 5 + [C.POINTER(CtxLayout)]),
+    "mgacbam_forward": (C.c_int, [C.POINTER(FwdLevel), C.c_int, C.c_void_p]),
+    "mgacbam_backward": (C.c_int, [C.POINTER(BwdLevel), C.c_int, C.c_void_p]),
+    "mgacbam_resize_nearest": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libmgacbam.so (once).  Raises LibraryMissing with the build command if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise LibraryMissing(
+                f"{LIB_PATH} not found: the HIP library is required (there is no fallback path). "
+                "Build it with `python -m mga_yolo_amd.build` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+        import torch  # noqa: F401  -- loads torch's libamdhip64.so.7 first so the library binds to the same HIP runtime
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise LibraryMissing(f"{LIB_PATH} does not export {name}; rebuild it") from e
+            fn.restype, fn.argtypes = res, args
+        v = lib.mgacbam_abi_version()
+        if v != ABI_VERSION:
+            raise LibraryMissing(f"{LIB_PATH} has ABI version {v}, expected {ABI_VERSION}; rebuild it")
+        _lib = lib
+        return lib
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().mgacbam_last_error().decode(errors="replace")
+        kind = "argument error" if rc < 0 else "HIP error"
+        raise RuntimeError(f"{what}: {kind} {rc}: {msg}")
+
+
+def ctx_bytes(B, Cc, H, W, hidden) -> int:
+    n = load().mgacbam_ctx_bytes(B, Cc, H, W, hidden)
+    if n == 0:
+        check(-2, "mgacbam_ctx_bytes")
+    return n
+
+
+def scratch_bytes(B, Cc, H, W, hidden, k) -> int:
+    n = load().mgacbam_bwd_scratch_bytes(B, Cc, H, W, hidden, k)
+    if n == 0:
+        check(-2, "mgacbam_bwd_scratch_bytes")
+    return n
+
+
+def ctx_layout(B, Cc, H, W, hidden) -> dict:
+    L = CtxLayout()
+    check(load().mgacbam_ctx_layout(B, Cc, H, W, hidden, C.byref(L)), "mgacbam_ctx_layout")
+    return {n: getattr(L, n) for n in CTX_FIELDS}

@@ -1,0 +1,67 @@
+// Kernel argument blocks (passed by value) and the ctx / scratch layouts shared by host and device code.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mgacbam {
+
+struct Geo {
+  int B, C, H, W, HW;
+  int hidden, k;
+  int use_sigmoid;
+  float thr, eps;
+};
+
+// saved statistics (device pointers into the caller's ctx buffer) -- see mgacbam_ctx_layout_t
+struct CtxPtrs {
+  float* S; float* use; float* den;
+  float* avg; float* mx; float* mavg;
+  int* valid; int* amax;
+  float* h_avg; float* h_mx; float* ca;
+  float* planes; int* cidx; float* sa;
+};
+
+struct ParamPtrs { const float* w1; const float* b1; const float* w2; const float* b2; const float* wsa; const float* beta; };
+
+// launch geometry chosen on the host (api.hip: choose_*); TX = lanes along H*W, power of two
+struct Tune {
+  int pool_tx;     // k_pool / k_bwd_reduce2 : rows of TX lanes sweep H*W, TY = 256/TX rows x CPT channels
+  int pool_cpt;
+  int apply_tx;    // k_apply
+  int apply_cpt;
+  int chan_tx;     // k_chan / k_bwd_reduce1 / k_bwd_apply : one H*W vector per lane, TY = 256/TX channel slices
+  int conv_twq;    // conv tiles: TWQ quads (4 px) wide, TH rows
+  int conv_th;
+};
+
+struct FwdArgs {
+  const void* x; const float* mask; void* y;
+  CtxPtrs c; ParamPtrs p; Geo g; Tune t;
+};
+
+// transient backward buffers (device pointers into the caller's scratch buffer)
+struct ScratchPtrs {
+  float* A_part;    // (B,C,nt)  sum over one hw tile of gy*x*sa
+  float* Q_part;    // (B,C,nt)  sum over one hw tile of gy*x
+  float* gpre;      // (B,HW)    dL/d(conv output)
+  float* gplanes;   // (B,3,HW)  dL/d(planes)
+  float* gwsa_part; // (nconv, 3*k*k)
+  float* gz;        // (B,C)     dL/dz
+  float* gbq;       // (B,C)     ca*A - Q  (for dL/dbeta)
+  float* gh_avg;    // (B,hidden)
+  float* gh_mx;     // (B,hidden)
+  float* chan4;     // (B,C,4)   {ca, g_avg, g_mx at arg-max, g_mx / N when GAP fallback}
+  float* Kb;        // (B)       sum_c g_avg * mavg * [S >= eps]
+};
+
+struct BwdArgs {
+  const void* x; const float* mask; const void* gy; void* gx; float* gmask;
+  float* gw1; float* gb1; float* gw2; float* gb2; float* gwsa; float* gbeta;
+  CtxPtrs c; ParamPtrs p; ScratchPtrs s; Geo g; Tune t;
+  int nt;       // hw tiles of k_bwd_reduce1
+  int nconv;    // workgroups of k_bwd_convT
+};
+
+static inline size_t align16(size_t v) { return (v + 15) & ~size_t(15); }
+
+}  // namespace mgacbam

@@ -1,0 +1,149 @@
+// Device helpers shared by the forward and backward kernels (gfx950 / CDNA4 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <float.h>
+#include <stdint.h>
+
+namespace mgacbam {
+
+constexpr int kBlock = 256;        // every kernel uses 256-thread workgroups = 4 waves
+constexpr int kWave = 64;
+using bf16_t = __hip_bfloat16;
+
+// ---------------------------------------------------------------------------------------------
+// element I/O: T in {float, __half, __hip_bfloat16}; arithmetic is always fp32
+// ---------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(v); }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return __bfloat162float(v); }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half from_f32<__half>(float v) { return __float2half_rn(v); }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return __float2bfloat16(v); }
+
+template <typename T, int VEC> struct alignas(sizeof(T) * VEC) Pack { T v[VEC]; };
+
+// one VEC-wide (4 x fp32 = 16 B, 4 x half = 8 B) coalesced load / store per lane
+template <typename T, int VEC>
+__device__ __forceinline__ void load_vec(const T* __restrict__ p, float (&out)[VEC]) {
+  Pack<T, VEC> r = *reinterpret_cast<const Pack<T, VEC>*>(p);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) out[e] = to_f32<T>(r.v[e]);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_vec(T* __restrict__ p, const float (&in)[VEC]) {
+  Pack<T, VEC> r;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) r.v[e] = from_f32<T>(in[e]);
+  *reinterpret_cast<Pack<T, VEC>*>(p) = r;
+}
+template <int VEC>
+__device__ __forceinline__ void load_ivec(const int* __restrict__ p, int (&out)[VEC]) {
+  Pack<int, VEC> r = *reinterpret_cast<const Pack<int, VEC>*>(p);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) out[e] = r.v[e];
+}
+template <int VEC>
+__device__ __forceinline__ void store_ivec(int* __restrict__ p, const int (&in)[VEC]) {
+  Pack<int, VEC> r;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) r.v[e] = in[e];
+  *reinterpret_cast<Pack<int, VEC>*>(p) = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scalar math
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// torch.nn.functional.softplus(beta=1, threshold=20)  (masked_cbam.py:150-152)
+__device__ __forceinline__ float softplusf_(float v) { return v > 20.0f ? v : log1pf(expf(v)); }
+// torch.isclose(a, b) with the default rtol=1e-5, atol=1e-8 (masked_cbam.py:120)
+__device__ __forceinline__ bool isclosef_(float a, float b) { return fabsf(a - b) <= 1e-8f + 1e-5f * fabsf(b); }
+
+// ---------------------------------------------------------------------------------------------
+// reductions.  Threads of a workgroup are laid out as TY rows of TX lanes, TX a power of two in
+// [1,256], row = tid / TX.  A "row reduction" combines the TX lanes of one row: xor-shuffles inside a
+// wave (groups are TX-aligned so xor offsets < TX never leave the group) and, when a row spans
+// several waves (TX = 128, 256), a second step through LDS.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_group_sum(float v, int width) {
+  for (int o = (width < kWave ? width : kWave) >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+  return v;
+}
+// (value, index) arg-max with first-index tie break: larger value wins, equal values -> smaller index
+__device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int oi) {
+  if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+__device__ __forceinline__ void wave_group_argmax(float& v, int& i, int width) {
+  for (int o = (width < kWave ? width : kWave) >> 1; o > 0; o >>= 1) {
+    float ov = __shfl_xor(v, o, kWave);
+    int oi = __shfl_xor(i, o, kWave);
+    argmax_combine(v, i, ov, oi);
+  }
+}
+
+// Row-sum of n values per thread.  `red` = LDS scratch of at least n * (kBlock / kWave) floats, used only
+// when TX > 64.  The result is valid in the first lane of each row (tx == 0).  All threads must call.
+template <int N>
+__device__ __forceinline__ void row_sum(float (&v)[N], int TX, int tid, float* red) {
+#pragma unroll
+  for (int n = 0; n < N; ++n) v[n] = wave_group_sum(v[n], TX);
+  if (TX > kWave) {                       // uniform per launch
+    const int wave = tid >> 6, lane = tid & 63;
+    __syncthreads();                       // red may still be in use by a previous call
+    if (lane == 0) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) red[wave * N + n] = v[n];
+    }
+    __syncthreads();
+    const int waves_per_row = TX >> 6;
+    if ((tid & (TX - 1)) == 0) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        float a = red[wave * N + n];
+        for (int w = 1; w < waves_per_row; ++w) a += red[(wave + w) * N + n];
+        v[n] = a;
+      }
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ void row_argmax(float (&v)[N], int (&idx)[N], int TX, int tid, float* red) {
+#pragma unroll
+  for (int n = 0; n < N; ++n) wave_group_argmax(v[n], idx[n], TX);
+  if (TX > kWave) {
+    const int wave = tid >> 6, lane = tid & 63;
+    int* redi = reinterpret_cast<int*>(red) + N * (kBlock / kWave);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) { red[wave * N + n] = v[n]; redi[wave * N + n] = idx[n]; }
+    }
+    __syncthreads();
+    const int waves_per_row = TX >> 6;
+    if ((tid & (TX - 1)) == 0) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        for (int w = 1; w < waves_per_row; ++w) argmax_combine(v[n], idx[n], red[(wave + w) * N + n], redi[(wave + w) * N + n]);
+      }
+    }
+  }
+}
+
+// whole-workgroup sum (result valid in thread 0); red >= kBlock/kWave floats
+__device__ __forceinline__ float block_sum(float v, int tid, float* red) {
+  v = wave_group_sum(v, kWave);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  if (tid == 0) { v = red[0]; for (int w = 1; w < kBlock / kWave; ++w) v += red[w]; }
+  return v;
+}
+
+__device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
+
+}  // namespace mgacbam

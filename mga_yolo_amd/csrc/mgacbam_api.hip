@@ -1,0 +1,393 @@
+// C ABI of libmgacbam.so (declared in include/mgacbam.h): argument checking, ctx/scratch layout, launch geometry
+// and kernel dispatch.  No allocation, no host<->device copy, no synchronisation: every entry point only enqueues
+// kernels on the caller's stream, so calls are re-entrant and graph-capturable.
+#include "../../include/mgacbam.h"
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "args.cuh"
+#include "bwd.cuh"
+#include "common.cuh"
+#include "fwd.cuh"
+
+using namespace mgacbam;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+static int launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(static_cast<int>(e), "%s: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int mgacbam_abi_version(void) { return MGACBAM_ABI_VERSION; }
+extern "C" const char* mgacbam_last_error(void) { return g_err; }
+extern "C" const char* mgacbam_build_info(void) {
+  return "libmgacbam gfx950 (CDNA4) hip " __VERSION__ " built " __DATE__;
+}
+
+// ------------------------------------------------------------------------------------------------
+// layouts
+// ------------------------------------------------------------------------------------------------
+static int check_shape(int B, int C, int H, int W, int hidden, int k) {
+  if (B < 1 || C < 1 || H < 1 || W < 1 || hidden < 1 || hidden > 4096 || C > 65536)
+    return fail(MGACBAM_E_SHAPE, "bad shape B=%d C=%d H=%d W=%d hidden=%d", B, C, H, W, hidden);
+  if (static_cast<long long>(H) * W > (1ll << 30) || static_cast<long long>(B) * C * H * W > (1ll << 40))
+    return fail(MGACBAM_E_SHAPE, "tensor too large B=%d C=%d H=%d W=%d", B, C, H, W);
+  if (k < 1 || k > 15 || (k & 1) == 0) return fail(MGACBAM_E_SHAPE, "spatial kernel k=%d must be odd and in 1..15", k);
+  return 0;
+}
+
+static void ctx_layout(int B, int C, int H, int W, int hidden, mgacbam_ctx_layout_t* L) {
+  const size_t HW = static_cast<size_t>(H) * W;
+  size_t o = 0;
+  auto take = [&](size_t n_elems) { size_t at = o; o = align16(o + n_elems * 4); return static_cast<int64_t>(at); };
+  L->S = take(B); L->use = take(B); L->den = take(B);
+  L->avg = take(static_cast<size_t>(B) * C); L->mx = take(static_cast<size_t>(B) * C); L->mavg = take(static_cast<size_t>(B) * C);
+  L->valid = take(static_cast<size_t>(B) * C); L->amax = take(static_cast<size_t>(B) * C);
+  L->h_avg = take(static_cast<size_t>(B) * hidden); L->h_mx = take(static_cast<size_t>(B) * hidden);
+  L->ca = take(static_cast<size_t>(B) * C);
+  L->planes = take(static_cast<size_t>(B) * 3 * HW);
+  L->cidx = take(static_cast<size_t>(B) * HW);
+  L->sa = take(static_cast<size_t>(B) * HW);
+  L->total = static_cast<int64_t>(o);
+}
+
+static CtxPtrs ctx_ptrs(void* base, int B, int C, int H, int W, int hidden) {
+  mgacbam_ctx_layout_t L;
+  ctx_layout(B, C, H, W, hidden, &L);
+  char* p = static_cast<char*>(base);
+  CtxPtrs c;
+  c.S = reinterpret_cast<float*>(p + L.S); c.use = reinterpret_cast<float*>(p + L.use); c.den = reinterpret_cast<float*>(p + L.den);
+  c.avg = reinterpret_cast<float*>(p + L.avg); c.mx = reinterpret_cast<float*>(p + L.mx); c.mavg = reinterpret_cast<float*>(p + L.mavg);
+  c.valid = reinterpret_cast<int*>(p + L.valid); c.amax = reinterpret_cast<int*>(p + L.amax);
+  c.h_avg = reinterpret_cast<float*>(p + L.h_avg); c.h_mx = reinterpret_cast<float*>(p + L.h_mx);
+  c.ca = reinterpret_cast<float*>(p + L.ca);
+  c.planes = reinterpret_cast<float*>(p + L.planes); c.cidx = reinterpret_cast<int*>(p + L.cidx); c.sa = reinterpret_cast<float*>(p + L.sa);
+  return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch geometry
+// ------------------------------------------------------------------------------------------------
+static int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
+static int pow2_ceil(int v) { int p = 1; while (p < v) p *= 2; return p; }
+static int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+static bool is_pow2_in(int v, int lo, int hi) { return v >= lo && v <= hi && (v & (v - 1)) == 0; }
+
+static int vec_of(int H, int W) { return ((static_cast<long long>(H) * W) % 4 == 0) ? 4 : 1; }
+
+static Tune choose_tune(int B, int C, int H, int W) {
+  const int HW = H * W, VEC = vec_of(H, W), nv = HW / VEC;
+  Tune t;
+  // rows of TX lanes sweep H*W: aim for >= 4 sweeps per lane, then shrink channels/row until the grid fills the chip
+  int tx = pow2_floor(nv / 4 > 0 ? nv / 4 : 1);
+  if (tx > 256) tx = 256;
+  int cpt = 4;
+  while (cpt > 1 && static_cast<long long>(B) * ((C + (256 / tx) * cpt - 1) / ((256 / tx) * cpt)) < 1024) cpt /= 2;
+  t.pool_tx = tx; t.pool_cpt = cpt;
+  t.apply_tx = tx; t.apply_cpt = cpt;
+  // one H*W vector per lane, TY channel slices: TX <= 64 so row reductions are pure wave shuffles
+  int ctx = pow2_ceil(nv) < 64 ? pow2_ceil(nv) : 64;
+  while (ctx > 16 && static_cast<long long>(B) * ((nv + ctx - 1) / ctx) < 768) ctx /= 2;
+  while (ctx < 64 && (256 / ctx) * 4 > C) ctx *= 2;       // keep >= 4 channels per row
+  t.chan_tx = ctx;
+  // conv tiles: full rows when W <= 128, otherwise equal column strips; 4 px per thread
+  const int ntx = (W + 127) / 128;
+  const int tw = (((W + ntx - 1) / ntx) + 3) / 4 * 4;
+  t.conv_twq = tw / 4;
+  int th = 256 / t.conv_twq;
+  if (th > H) th = H;
+  if (th > 64) th = 64;
+  if (th < 1) th = 1;
+  t.conv_th = th;
+  // experiment hooks (tests / tuning sweeps); ignored when not a legal value
+  int v;
+  if (is_pow2_in(v = env_int("MGACBAM_POOL_TX", 0), 1, 256)) t.pool_tx = v;
+  if ((v = env_int("MGACBAM_POOL_CPT", 0)) == 1 || v == 2 || v == 4) t.pool_cpt = v;
+  if (is_pow2_in(v = env_int("MGACBAM_APPLY_TX", 0), 1, 256)) t.apply_tx = v;
+  if ((v = env_int("MGACBAM_APPLY_CPT", 0)) == 1 || v == 2 || v == 4) t.apply_cpt = v;
+  if (is_pow2_in(v = env_int("MGACBAM_CHAN_TX", 0), 1, 64)) t.chan_tx = v;
+  return t;
+}
+
+static int conv_tiles(const Tune& t, int H, int W) {
+  const int TW = t.conv_twq * 4;
+  return ((W + TW - 1) / TW) * ((H + t.conv_th - 1) / t.conv_th);
+}
+static int chan_tiles(const Tune& t, int H, int W) {
+  const int nv = H * W / vec_of(H, W);
+  return (nv + t.chan_tx - 1) / t.chan_tx;
+}
+
+struct ScratchLayout { size_t A_part, Q_part, gpre, gplanes, gwsa_part, gz, gbq, gh_avg, gh_mx, chan4, Kb, total; };
+static ScratchLayout scratch_layout(int B, int C, int H, int W, int hidden, int k) {
+  const Tune t = choose_tune(B, C, H, W);
+  const size_t HW = static_cast<size_t>(H) * W, BC = static_cast<size_t>(B) * C;
+  const size_t nt = chan_tiles(t, H, W), nconv = static_cast<size_t>(B) * conv_tiles(t, H, W);
+  ScratchLayout L;
+  size_t o = 0;
+  auto take = [&](size_t n_elems) { size_t at = o; o = align16(o + n_elems * 4); return at; };
+  L.A_part = take(BC * nt); L.Q_part = take(BC * nt);
+  L.gpre = take(B * HW); L.gplanes = take(static_cast<size_t>(B) * 3 * HW);
+  L.gwsa_part = take(nconv * 3 * k * k);
+  L.gz = take(BC); L.gbq = take(BC);
+  L.gh_avg = take(static_cast<size_t>(B) * hidden); L.gh_mx = take(static_cast<size_t>(B) * hidden);
+  L.chan4 = take(BC * 4); L.Kb = take(B);
+  L.total = o;
+  return L;
+}
+
+extern "C" size_t mgacbam_ctx_bytes(int B, int C, int H, int W, int hidden) {
+  if (check_shape(B, C, H, W, hidden, 7)) return 0;
+  mgacbam_ctx_layout_t L;
+  ctx_layout(B, C, H, W, hidden, &L);
+  return static_cast<size_t>(L.total);
+}
+extern "C" int mgacbam_ctx_layout(int B, int C, int H, int W, int hidden, mgacbam_ctx_layout_t* out) {
+  if (!out) return fail(MGACBAM_E_NULL, "out is NULL");
+  if (int e = check_shape(B, C, H, W, hidden, 7)) return e;
+  ctx_layout(B, C, H, W, hidden, out);
+  return 0;
+}
+extern "C" size_t mgacbam_bwd_scratch_bytes(int B, int C, int H, int W, int hidden, int k) {
+  if (check_shape(B, C, H, W, hidden, k)) return 0;
+  return scratch_layout(B, C, H, W, hidden, k).total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dispatch helpers
+// ------------------------------------------------------------------------------------------------
+static size_t elem_size(int dtype) { return dtype == MGACBAM_F32 ? 4 : 2; }
+static bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+#define LAUNCH(kernel, grid, smem, stream, args) hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), smem, stream, args)
+
+// T x VEC
+#define DISPATCH_T_VEC(dtype, VECV, CALL)                                                         \
+  do {                                                                                            \
+    if ((dtype) == MGACBAM_F32) { if ((VECV) == 4) { CALL(float, 4); } else { CALL(float, 1); } }  \
+    else if ((dtype) == MGACBAM_F16) { if ((VECV) == 4) { CALL(__half, 4); } else { CALL(__half, 1); } } \
+    else { if ((VECV) == 4) { CALL(bf16_t, 4); } else { CALL(bf16_t, 1); } }          \
+  } while (0)
+
+#define DISPATCH_CPT(CPTV, CALL2)                                              \
+  do { if ((CPTV) == 4) { CALL2(4); } else if ((CPTV) == 2) { CALL2(2); } else { CALL2(1); } } while (0)
+
+static Geo make_geo(int B, int C, int H, int W, const mgacbam_params_t& p) {
+  Geo g;
+  g.B = B; g.C = C; g.H = H; g.W = W; g.HW = H * W; g.hidden = p.hidden; g.k = p.k;
+  g.use_sigmoid = p.use_sigmoid_mask; g.thr = p.tiny_thr; g.eps = p.eps;
+  return g;
+}
+static ParamPtrs make_params(const mgacbam_params_t& p) { return ParamPtrs{p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta}; }
+static int check_params(const mgacbam_params_t& p) {
+  if (!p.w1 || !p.b1 || !p.w2 || !p.b2 || !p.wsa || !p.beta) return fail(MGACBAM_E_NULL, "NULL parameter pointer");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+static int forward_level(const mgacbam_fwd_level_t& L, hipStream_t st) {
+  if (!L.x || !L.y || !L.ctx) return fail(MGACBAM_E_NULL, "forward: x / y / ctx is NULL");
+  if (int e = check_params(L.p)) return e;
+  if (int e = check_shape(L.B, L.C, L.H, L.W, L.p.hidden, L.p.k)) return e;
+  if (L.dtype < MGACBAM_F32 || L.dtype > MGACBAM_BF16) return fail(MGACBAM_E_DTYPE, "forward: dtype %d", L.dtype);
+  const int VEC = vec_of(L.H, L.W);
+  const size_t need = VEC * elem_size(L.dtype);
+  if (!aligned_to(L.x, need) || !aligned_to(L.y, need) || !aligned_to(L.ctx, 16) || (L.mask && !aligned_to(L.mask, VEC * 4)))
+    return fail(MGACBAM_E_ALIGN, "forward: x/y must be %zu-byte aligned, ctx 16-byte, mask %d-byte", need, VEC * 4);
+
+  FwdArgs A;
+  A.x = L.x; A.mask = L.mask; A.y = L.y;
+  A.c = ctx_ptrs(L.ctx, L.B, L.C, L.H, L.W, L.p.hidden);
+  A.p = make_params(L.p);
+  A.g = make_geo(L.B, L.C, L.H, L.W, L.p);
+  A.t = choose_tune(L.B, L.C, L.H, L.W);
+  const Geo& g = A.g;
+  const int nv = g.HW / VEC;
+  const bool has_mask = L.mask != nullptr;
+
+  {  // 1. pooling
+    const int TY = kBlock / A.t.pool_tx, CPB = TY * A.t.pool_cpt;
+    const int grid = g.B * ((g.C + CPB - 1) / CPB);
+#define CALL_POOL2(CPTV) if (has_mask) LAUNCH((k_pool<TT, VV, CPTV, true>), grid, 0, st, A); else LAUNCH((k_pool<TT, VV, CPTV, false>), grid, 0, st, A)
+#define CALL_POOL(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; DISPATCH_CPT(A.t.pool_cpt, CALL_POOL2); }
+    DISPATCH_T_VEC(L.dtype, VEC, CALL_POOL);
+#undef CALL_POOL
+#undef CALL_POOL2
+    if (int e = launch_status("k_pool")) return e;
+  }
+  {  // 2. shared MLP + channel gate
+    const size_t smem = (2 * static_cast<size_t>(g.C) + 2 * g.hidden) * sizeof(float);
+    LAUNCH(k_mlp_fwd, g.B, smem, st, A);
+    if (int e = launch_status("k_mlp_fwd")) return e;
+  }
+  {  // 3. channel max / mean planes
+    const int grid = g.B * ((nv + A.t.chan_tx - 1) / A.t.chan_tx);
+#define CALL_CHAN(Tt, Vv) LAUNCH((k_chan<Tt, Vv>), grid, 0, st, A)
+    DISPATCH_T_VEC(L.dtype, VEC, CALL_CHAN);
+#undef CALL_CHAN
+    if (int e = launch_status("k_chan")) return e;
+  }
+  {  // 4. k x k conv + sigmoid
+    const int grid = g.B * conv_tiles(A.t, g.H, g.W);
+    const size_t smem = 3 * static_cast<size_t>(A.t.conv_th + g.k - 1) * (A.t.conv_twq * 4 + g.k - 1) * sizeof(float);
+    switch (g.k) {
+      case 3: LAUNCH(k_conv_fwd<3>, grid, smem, st, A); break;
+      case 5: LAUNCH(k_conv_fwd<5>, grid, smem, st, A); break;
+      case 7: LAUNCH(k_conv_fwd<7>, grid, smem, st, A); break;
+      default: LAUNCH(k_conv_fwd<0>, grid, smem, st, A); break;
+    }
+    if (int e = launch_status("k_conv_fwd")) return e;
+  }
+  {  // 5. apply both gates + alpha residual
+    const int TY = kBlock / A.t.apply_tx, CPB = TY * A.t.apply_cpt;
+    const int grid = g.B * ((g.C + CPB - 1) / CPB);
+#define CALL_APPLY2(CPTV) LAUNCH((k_apply<TT, VV, CPTV>), grid, 0, st, A)
+#define CALL_APPLY(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; DISPATCH_CPT(A.t.apply_cpt, CALL_APPLY2); }
+    DISPATCH_T_VEC(L.dtype, VEC, CALL_APPLY);
+#undef CALL_APPLY
+#undef CALL_APPLY2
+    if (int e = launch_status("k_apply")) return e;
+  }
+  return 0;
+}
+
+extern "C" int mgacbam_forward(const mgacbam_fwd_level_t* levels, int n_levels, void* stream) {
+  if (!levels) return fail(MGACBAM_E_NULL, "levels is NULL");
+  if (n_levels < 1 || n_levels > MGACBAM_MAX_LEVELS) return fail(MGACBAM_E_LEVELS, "n_levels=%d", n_levels);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int l = 0; l < n_levels; ++l)
+    if (int e = forward_level(levels[l], st)) return e;
+  g_err[0] = 0;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+static int backward_level(const mgacbam_bwd_level_t& L, hipStream_t st) {
+  if (!L.x || !L.gy || !L.ctx || !L.scratch || !L.gx) return fail(MGACBAM_E_NULL, "backward: x / gy / ctx / scratch / gx is NULL");
+  if (!L.gw1 || !L.gb1 || !L.gw2 || !L.gb2 || !L.gwsa || !L.gbeta) return fail(MGACBAM_E_NULL, "backward: NULL parameter-gradient pointer");
+  if (L.gmask && !L.mask) return fail(MGACBAM_E_NULL, "backward: gmask requested but mask is NULL");
+  if (int e = check_params(L.p)) return e;
+  if (int e = check_shape(L.B, L.C, L.H, L.W, L.p.hidden, L.p.k)) return e;
+  if (L.dtype < MGACBAM_F32 || L.dtype > MGACBAM_BF16) return fail(MGACBAM_E_DTYPE, "backward: dtype %d", L.dtype);
+  const int VEC = vec_of(L.H, L.W);
+  const size_t need = VEC * elem_size(L.dtype);
+  if (!aligned_to(L.x, need) || !aligned_to(L.gy, need) || !aligned_to(L.gx, need) || !aligned_to(L.ctx, 16) ||
+      !aligned_to(L.scratch, 16) || (L.gmask && !aligned_to(L.gmask, VEC * 4)))
+    return fail(MGACBAM_E_ALIGN, "backward: x/gy/gx must be %zu-byte aligned, ctx/scratch 16-byte", need);
+
+  BwdArgs A;
+  A.x = L.x; A.mask = L.mask; A.gy = L.gy; A.gx = L.gx; A.gmask = L.gmask;
+  A.gw1 = L.gw1; A.gb1 = L.gb1; A.gw2 = L.gw2; A.gb2 = L.gb2; A.gwsa = L.gwsa; A.gbeta = L.gbeta;
+  A.c = ctx_ptrs(const_cast<void*>(L.ctx), L.B, L.C, L.H, L.W, L.p.hidden);
+  A.p = make_params(L.p);
+  A.g = make_geo(L.B, L.C, L.H, L.W, L.p);
+  A.t = choose_tune(L.B, L.C, L.H, L.W);
+  const Geo& g = A.g;
+  const ScratchLayout SL = scratch_layout(L.B, L.C, L.H, L.W, L.p.hidden, L.p.k);
+  char* sp = static_cast<char*>(L.scratch);
+  A.s.A_part = reinterpret_cast<float*>(sp + SL.A_part); A.s.Q_part = reinterpret_cast<float*>(sp + SL.Q_part);
+  A.s.gpre = reinterpret_cast<float*>(sp + SL.gpre); A.s.gplanes = reinterpret_cast<float*>(sp + SL.gplanes);
+  A.s.gwsa_part = reinterpret_cast<float*>(sp + SL.gwsa_part);
+  A.s.gz = reinterpret_cast<float*>(sp + SL.gz); A.s.gbq = reinterpret_cast<float*>(sp + SL.gbq);
+  A.s.gh_avg = reinterpret_cast<float*>(sp + SL.gh_avg); A.s.gh_mx = reinterpret_cast<float*>(sp + SL.gh_mx);
+  A.s.chan4 = reinterpret_cast<float*>(sp + SL.chan4); A.s.Kb = reinterpret_cast<float*>(sp + SL.Kb);
+  A.nt = chan_tiles(A.t, g.H, g.W);
+  A.nconv = g.B * conv_tiles(A.t, g.H, g.W);
+  const bool want_gmask = L.gmask != nullptr;
+
+  {  // 1. per-(b,c) and per-pixel reductions of gy*x
+    const int grid = g.B * A.nt;
+#define CALL_R1(Tt, Vv) LAUNCH((k_bwd_reduce1<Tt, Vv>), grid, 0, st, A)
+    DISPATCH_T_VEC(L.dtype, VEC, CALL_R1);
+#undef CALL_R1
+    if (int e = launch_status("k_bwd_reduce1")) return e;
+  }
+  {  // 2. transposed conv + dWsa partials
+    const size_t smem = 4 * static_cast<size_t>(A.t.conv_th + g.k - 1) * (A.t.conv_twq * 4 + g.k - 1) * sizeof(float);
+    switch (g.k) {
+      case 3: LAUNCH(k_bwd_convT<3>, A.nconv, smem, st, A); break;
+      case 5: LAUNCH(k_bwd_convT<5>, A.nconv, smem, st, A); break;
+      case 7: LAUNCH(k_bwd_convT<7>, A.nconv, smem, st, A); break;
+      default: LAUNCH(k_bwd_convT<0>, A.nconv, smem, st, A); break;
+    }
+    if (int e = launch_status("k_bwd_convT")) return e;
+  }
+  {  // 3. remaining part of g_ca (needs g_planes), g_z
+    const int TY = kBlock / A.t.pool_tx, CPB = TY * A.t.pool_cpt;
+    const int grid = g.B * ((g.C + CPB - 1) / CPB);
+#define CALL_R22(CPTV) LAUNCH((k_bwd_reduce2<TT, VV, CPTV>), grid, 0, st, A)
+#define CALL_R2(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; DISPATCH_CPT(A.t.pool_cpt, CALL_R22); }
+    DISPATCH_T_VEC(L.dtype, VEC, CALL_R2);
+#undef CALL_R2
+#undef CALL_R22
+    if (int e = launch_status("k_bwd_reduce2")) return e;
+  }
+  {  // 4. shared-MLP backward
+    const size_t smem = (static_cast<size_t>(g.C) + 2 * g.hidden) * sizeof(float);
+    LAUNCH(k_bwd_mlp, g.B, smem, st, A);
+    if (int e = launch_status("k_bwd_mlp")) return e;
+  }
+  {  // 5. gx (+ gmask)
+    const int grid = g.B * A.nt;
+#define CALL_AP(Tt, Vv) if (want_gmask) LAUNCH((k_bwd_apply<Tt, Vv, true>), grid, 0, st, A); else LAUNCH((k_bwd_apply<Tt, Vv, false>), grid, 0, st, A)
+    DISPATCH_T_VEC(L.dtype, VEC, CALL_AP);
+#undef CALL_AP
+    if (int e = launch_status("k_bwd_apply")) return e;
+  }
+  {  // 6. parameter gradients
+    const int total = 2 * g.C * g.hidden + g.C + g.hidden + 3 * g.k * g.k;
+    const int grid = (total + kBlock - 1) / kBlock + 1;
+    LAUNCH(k_bwd_finalize, grid, 0, st, A);
+    if (int e = launch_status("k_bwd_finalize")) return e;
+  }
+  return 0;
+}
+
+extern "C" int mgacbam_backward(const mgacbam_bwd_level_t* levels, int n_levels, void* stream) {
+  if (!levels) return fail(MGACBAM_E_NULL, "levels is NULL");
+  if (n_levels < 1 || n_levels > MGACBAM_MAX_LEVELS) return fail(MGACBAM_E_LEVELS, "n_levels=%d", n_levels);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int l = 0; l < n_levels; ++l)
+    if (int e = backward_level(levels[l], st)) return e;
+  g_err[0] = 0;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// nearest-neighbour resize (integer index path)
+// ------------------------------------------------------------------------------------------------
+extern "C" int mgacbam_resize_nearest(const float* src, float* dst, int n_planes, int in_h, int in_w, int out_h, int out_w,
+                                      void* stream) {
+  if (!src || !dst) return fail(MGACBAM_E_NULL, "resize: NULL pointer");
+  if (n_planes < 1 || in_h < 1 || in_w < 1 || out_h < 1 || out_w < 1) return fail(MGACBAM_E_SHAPE, "resize: bad shape");
+  const size_t total = static_cast<size_t>(n_planes) * out_h * out_w;
+  size_t grid = (total + kBlock - 1) / kBlock;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_resize_nearest, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                     src, dst, n_planes, in_h, in_w, out_h, out_w);
+  if (int e = launch_status("k_resize_nearest")) return e;
+  g_err[0] = 0;
+  return 0;
+}

@@ -1,0 +1,208 @@
+"""Autograd entry points of the mask-guided CBAM block on MI355X.
+
+``mask_cbam(x, mask, ...)`` replaces the body of the reference's ``MaskCBAM.forward``
+(mga_yolo/nn/modules/masked_cbam.py:154-171) for device tensors: forward and backward are each ONE call
+into libmgacbam.so (include/mgacbam.h), which enqueues the hand-written gfx950 kernels on the current stream.
+``mask_cbam_pyramid`` does the same for several independent pyramid levels (P3/P4/P5) in one call.
+
+Device tensors never take any other path: a missing library raises (``_lib.LibraryMissing``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+
+@dataclass(frozen=True)
+class BlockConfig:
+    """Non-tensor constructor state of one block (masked_cbam.py:34-50)."""
+    hidden: int
+    k: int = 7
+    use_sigmoid_mask: bool = True
+    tiny_thr: float = 1e-4
+    eps: float = 1e-6
+
+
+_DTYPES = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+SLOTS = 8  # tensors per level in the flat argument list: x, mask, w1, b1, w2, b2, wsa, beta
+
+
+def _aligned(t: torch.Tensor) -> torch.Tensor:
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone(memory_format=torch.contiguous_format)
+    return t
+
+
+def _check_level(x: torch.Tensor, mask: Optional[torch.Tensor], params: Sequence[torch.Tensor], cfg: BlockConfig):
+    if x.dim() != 4:
+        raise AssertionError("MaskCBAM expects a (B,C,H,W) feature")          # masked_cbam.py:160
+    if x.dtype not in _DTYPES:
+        raise TypeError(f"unsupported feature dtype {x.dtype}")
+    B, Cc, H, W = x.shape
+    if mask is not None:
+        m = mask.unsqueeze(1) if mask.dim() == 3 else mask                    # masked_cbam.py:81-85
+        if tuple(m.shape) != (B, 1, H, W):                                    # the reference's expand() raises too
+            raise RuntimeError(f"mask shape {tuple(mask.shape)} does not match feature (B,1,H,W)=({B},1,{H},{W})")
+    w1, b1, w2, b2, wsa, beta = params
+    h, k = cfg.hidden, cfg.k
+    want = {"w1": (h, Cc), "b1": (h,), "w2": (Cc, h), "b2": (Cc,), "wsa": (1, 3, k, k), "beta": ()}
+    for name, t in zip(want, params):
+        if tuple(t.shape) != want[name] or t.dtype != torch.float32 or t.device != x.device:
+            raise ValueError(f"parameter {name}: expected fp32 {want[name]} on {x.device}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+
+
+def _params_struct(params: Sequence[torch.Tensor], cfg: BlockConfig) -> _lib.Params:
+    w1, b1, w2, b2, wsa, beta = params
+    return _lib.Params(w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), wsa.data_ptr(), beta.data_ptr(),
+                       cfg.hidden, cfg.k, int(cfg.use_sigmoid_mask), cfg.tiny_thr, cfg.eps)
+
+
+class _PyramidFn(torch.autograd.Function):
+    """n independent levels; flat inputs = n x (x, mask|None, w1, b1, w2, b2, wsa, beta)."""
+
+    @staticmethod
+    def forward(ctx, cfgs: Tuple[BlockConfig, ...], *flat):
+        n = len(cfgs)
+        assert len(flat) == n * SLOTS and 1 <= n <= _lib.MAX_LEVELS
+        lib = _lib.load()
+        levels = (_lib.FwdLevel * n)()
+        keep: List[Optional[torch.Tensor]] = []
+        outs, meta = [], []
+        dev = flat[0].device
+        for l in range(n):
+            x, mask, *params = flat[l * SLOTS:(l + 1) * SLOTS]
+            cfg = cfgs[l]
+            if not x.is_cuda or x.device != dev:
+                raise RuntimeError("mask_cbam: all features must live on the same GPU")
+            _check_level(x, mask, params, cfg)
+            B, Cc, H, W = x.shape
+            xc = _aligned(x.detach())
+            m32 = None if mask is None else _aligned(mask.detach().reshape(B, 1, H, W).float())
+            pc = [_aligned(p.detach()) for p in params]
+            y = torch.empty_like(xc)
+            cbuf = torch.empty(_lib.ctx_bytes(B, Cc, H, W, cfg.hidden), dtype=torch.uint8, device=dev)
+            L = levels[l]
+            L.x, L.mask, L.y, L.ctx = xc.data_ptr(), (None if m32 is None else m32.data_ptr()), y.data_ptr(), cbuf.data_ptr()
+            L.p = _params_struct(pc, cfg)
+            L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[x.dtype]
+            keep += [xc, m32, cbuf, *pc]
+            outs.append(y)
+            meta.append((None if mask is None else (mask.dtype, tuple(mask.shape))))
+        with torch.cuda.device(dev):
+            _lib.check(lib.mgacbam_forward(levels, n, torch.cuda.current_stream(dev).cuda_stream), "mgacbam_forward")
+        ctx.save_for_backward(*keep)
+        ctx.cfgs, ctx.meta = cfgs, meta
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        cfgs, n = ctx.cfgs, len(ctx.cfgs)
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        per = 3 + 6
+        levels = (_lib.BwdLevel * n)()
+        grads: List[Optional[torch.Tensor]] = [None]
+        hold = []
+        dev = saved[0].device
+        for l in range(n):
+            xc, m32, cbuf, *pc = saved[l * per:(l + 1) * per]
+            cfg = cfgs[l]
+            B, Cc, H, W = xc.shape
+            gy = gys[l]
+            gy = torch.zeros_like(xc) if gy is None else _aligned(gy.to(xc.dtype))
+            want_gmask = m32 is not None and ctx.needs_input_grad[1 + l * SLOTS + 1]
+            gx = torch.empty_like(xc)
+            gmask = torch.empty_like(m32) if want_gmask else None
+            pg = [torch.empty_like(p) for p in pc]
+            scratch = torch.empty(_lib.scratch_bytes(B, Cc, H, W, cfg.hidden, cfg.k), dtype=torch.uint8, device=dev)
+            L = levels[l]
+            L.x, L.mask, L.gy, L.ctx, L.scratch = (xc.data_ptr(), None if m32 is None else m32.data_ptr(), gy.data_ptr(),
+                                                   cbuf.data_ptr(), scratch.data_ptr())
+            L.gx, L.gmask = gx.data_ptr(), (None if gmask is None else gmask.data_ptr())
+            L.gw1, L.gb1, L.gw2, L.gb2, L.gwsa, L.gbeta = (t.data_ptr() for t in pg)
+            L.p = _params_struct(pc, cfg)
+            L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[xc.dtype]
+            hold += [gy, scratch]
+            if gmask is not None:
+                mdtype, mshape = ctx.meta[l]
+                gmask = gmask.reshape(mshape).to(mdtype)
+            grads += [gx, gmask, *pg]
+        with torch.cuda.device(dev):
+            _lib.check(lib.mgacbam_backward(levels, n, torch.cuda.current_stream(dev).cuda_stream), "mgacbam_backward")
+        del hold
+        return tuple(grads)
+
+
+def mask_cbam_pyramid(levels: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], Sequence[torch.Tensor], BlockConfig]]):
+    """levels: [(x, mask|None, (w1,b1,w2,b2,wsa,beta), BlockConfig), ...] -> tuple of outputs (one library call)."""
+    cfgs, flat = [], []
+    for x, mask, params, cfg in levels:
+        cfgs.append(cfg)
+        flat += [x, mask, *params]
+    return _PyramidFn.apply(tuple(cfgs), *flat)
+
+
+def mask_cbam(x: torch.Tensor, mask: Optional[torch.Tensor], w1, b1, w2, b2, wsa, beta, cfg: BlockConfig) -> torch.Tensor:
+    """y = x + softplus(beta) * (SAM(CAM(x, mask), mask) - x) for a device tensor x (B,C,H,W)."""
+    return _PyramidFn.apply((cfg,), x, mask, w1, b1, w2, b2, wsa, beta)[0]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# inspection helpers (tests / tooling): run the forward library call and view the saved statistics by name
+# ---------------------------------------------------------------------------------------------------------
+def forward_with_ctx(x, mask, params, cfg: BlockConfig):
+    """-> (y, {name: tensor view into ctx}) without autograd; names follow mgacbam_ctx_layout_t."""
+    lib = _lib.load()
+    _check_level(x, mask, params, cfg)
+    B, Cc, H, W = x.shape
+    xc = _aligned(x.detach())
+    m32 = None if mask is None else _aligned(mask.detach().reshape(B, 1, H, W).float())
+    pc = [_aligned(p.detach()) for p in params]
+    y = torch.empty_like(xc)
+    cbuf = torch.zeros(_lib.ctx_bytes(B, Cc, H, W, cfg.hidden), dtype=torch.uint8, device=x.device)
+    lv = (_lib.FwdLevel * 1)()
+    L = lv[0]
+    L.x, L.mask, L.y, L.ctx = xc.data_ptr(), (None if m32 is None else m32.data_ptr()), y.data_ptr(), cbuf.data_ptr()
+    L.p = _params_struct(pc, cfg)
+    L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[x.dtype]
+    with torch.cuda.device(x.device):
+        _lib.check(lib.mgacbam_forward(lv, 1, torch.cuda.current_stream(x.device).cuda_stream), "mgacbam_forward")
+    return y, ctx_views(cbuf, B, Cc, H, W, cfg.hidden)
+
+
+def ctx_views(cbuf: torch.Tensor, B, Cc, H, W, hidden) -> dict:
+    lay = _lib.ctx_layout(B, Cc, H, W, hidden)
+    HW = H * W
+    shapes = dict(S=(B,), use=(B,), den=(B,), avg=(B, Cc), mx=(B, Cc), mavg=(B, Cc), valid=(B, Cc), amax=(B, Cc),
+                  h_avg=(B, hidden), h_mx=(B, hidden), ca=(B, Cc), planes=(B, 3, HW), cidx=(B, HW), sa=(B, HW))
+    ints = {"valid", "amax", "cidx"}
+    out = {}
+    for name, shp in shapes.items():
+        n = 1
+        for s in shp:
+            n *= s
+        raw = cbuf[lay[name]: lay[name] + 4 * n]
+        out[name] = raw.view(torch.int32 if name in ints else torch.float32).reshape(shp)
+    return out
+
+
+def resize_nearest(src: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
+    """F.interpolate(src, (out_h,out_w), mode='nearest') for fp32 (...,H,W) device tensors: the integer index path of
+    mga_yolo/nn/losses/segmentation.py:103-110, bit-exact (pure gather)."""
+    if not src.is_cuda or src.dtype != torch.float32 or src.dim() < 2:
+        raise TypeError("resize_nearest expects an fp32 device tensor (..., H, W)")
+    lib = _lib.load()
+    s = _aligned(src)
+    in_h, in_w = s.shape[-2:]
+    planes = s.numel() // (in_h * in_w)
+    dst = torch.empty(*s.shape[:-2], out_h, out_w, dtype=torch.float32, device=s.device)
+    with torch.cuda.device(s.device):
+        _lib.check(lib.mgacbam_resize_nearest(s.data_ptr(), dst.data_ptr(), planes, in_h, in_w, out_h, out_w,
+                                              torch.cuda.current_stream(s.device).cuda_stream), "mgacbam_resize_nearest")
+    return dst

@@ -1,0 +1,37 @@
+"""Drop-in registration: make the reference engine build THIS MaskCBAM.
+
+``parse_model`` resolves the YAML string "MaskCBAM" with ``globals()[m]`` inside ``ultralytics.nn.tasks`` and picks the
+``[feat, mask]`` branch by identity ``m is MaskCBAM`` against the same module global (U/nn/tasks.py:1676-1682, 1733-1739),
+so rebinding that one global -- before ``YOLO(...)`` / ``MGAModel(...)`` is constructed -- is enough; the trainer's alpha
+logger finds the module by ``isinstance`` against ``mga_yolo.nn.modules.masked_cbam.MaskCBAM`` (mga_yolo/model/trainer.py:286-295),
+so that name is rebound as well.  Nothing else in the reference changes.  See INTEGRATION.md.
+"""
+from __future__ import annotations
+
+import importlib
+import sys
+from typing import List
+
+from .module import MaskCBAM
+
+_TARGETS = ("ultralytics.nn.tasks", "ultralytics.nn", "ultralytics.nn.modules",
+            "mga_yolo.nn.modules.masked_cbam", "mga_yolo.nn.modules", "mga_yolo.nn")
+
+
+def install(strict: bool = False) -> List[str]:
+    """Rebind ``MaskCBAM`` in every reference module that exports it.  Returns the module names patched.
+    ``strict=True`` raises if the parse_model namespace (ultralytics.nn.tasks) could not be patched."""
+    patched = []
+    for name in _TARGETS:
+        mod = sys.modules.get(name)
+        if mod is None:
+            try:
+                mod = importlib.import_module(name)
+            except Exception:
+                continue
+        if hasattr(mod, "MaskCBAM") or name == "ultralytics.nn.tasks":
+            setattr(mod, "MaskCBAM", MaskCBAM)
+            patched.append(name)
+    if strict and "ultralytics.nn.tasks" not in patched:
+        raise RuntimeError("ultralytics.nn.tasks is not importable: nothing to install into")
+    return patched

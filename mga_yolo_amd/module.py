@@ -1,0 +1,170 @@
+"""Host-side mirror of the reference's module interface for the hot path.
+
+``MaskCBAM`` keeps the contract of ``mga_yolo/nn/modules/masked_cbam.py:10-174``: same constructor signature and
+defaults, same parameter names / shapes / creation order (so the same seed gives the same initial values and reference
+checkpoints load: ``beta``, ``cam_mlp.0.{weight,bias}``, ``cam_mlp.2.{weight,bias}``, ``sam_conv.weight``), ``[feat, mask]``
+list input, ``alpha`` property, ``extra_repr``, plain-tensor output (forward hooks work), deepcopy / pickle safe (no ctypes
+state on the instance -- EMA deep-copies the module, U/utils/torch_utils.py:722).
+
+Device tensors run the hand-written HIP kernels through ``functional.mask_cbam`` (one library call forward, one backward).
+Host (CPU) tensors -- the 256x256 stride probe ``parse_model`` runs at build time (U/nn/tasks.py:413-429) and BASELINE
+config 0 (``device='cpu'``) -- run ``_host_forward``, a plain-PyTorch statement of the same mathematics; it is never
+used for a device tensor, and a device tensor with the library missing raises.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Sequence, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .functional import BlockConfig, mask_cbam
+
+_GATER_MODES = ("deterministic", "gumbel", "hard_st", "bernoulli_detach")
+
+
+class ProbMaskGater(nn.Module):
+    """Stochastic gate applied to the mask BEFORE the block when ``MGA_PROB_MODE`` is set
+    (reference mga_yolo/nn/modules/probmaskgater.py:8-98).  RNG-dependent, so it stays in PyTorch upstream of the kernels
+    (SURVEY 8a row a9): the input is clamped to [0,1] (note: applied to whatever the mask head emits, logits included),
+    eval / 'deterministic' return that, 'gumbel' adds logistic noise in logit space, 'hard_st' thresholds with a
+    straight-through gradient, 'bernoulli_detach' samples without gradient."""
+
+    def __init__(self, mode: str = "gumbel", tau: float = 1.0, p_min: float = 0.0, threshold: float = 0.5,
+                 seed: Optional[int] = None):
+        super().__init__()
+        if tau <= 0:
+            raise ValueError("tau must be > 0")
+        self.mode, self.tau, self.p_min, self.threshold, self._seed = mode, float(tau), float(p_min), float(threshold), seed
+        if seed is not None:
+            self.register_buffer("_ctr", torch.zeros((), dtype=torch.long))
+
+    def _generator(self, device):
+        if self._seed is None:
+            return None
+        g = torch.Generator(device=device)
+        g.manual_seed(self._seed + int(self._ctr.item()))
+        self._ctr.add_(1)
+        return g
+
+    def _soft_sample(self, p: torch.Tensor) -> torch.Tensor:
+        gen = self._generator(p.device)
+        lo, hi = 1e-6, 1.0 - 1e-6
+        u1 = torch.rand(p.shape, dtype=p.dtype, device=p.device, generator=gen).clamp_(lo, hi)
+        u2 = torch.rand(p.shape, dtype=p.dtype, device=p.device, generator=gen).clamp_(lo, hi)
+        noise = torch.log(-torch.log(u2)) - torch.log(-torch.log(u1))          # Gumbel(u1) - Gumbel(u2): logistic
+        q = p.clamp(lo, hi)
+        logit = torch.log(q) - torch.log1p(-q)
+        return torch.sigmoid((logit + noise) / self.tau)
+
+    def forward(self, p: torch.Tensor) -> torch.Tensor:
+        if p.dim() == 3:
+            p = p.unsqueeze(1)
+        p = p.float().clamp(0.0, 1.0)
+        if self.p_min > 0:
+            p = p.clamp_min(self.p_min)
+        if not self.training or self.mode == "deterministic":
+            return p
+        if self.mode == "gumbel":
+            return self._soft_sample(p)
+        if self.mode == "hard_st":
+            soft = self._soft_sample(p)
+            return (soft > self.threshold).float() + (soft - soft.detach())
+        if self.mode == "bernoulli_detach":
+            return torch.bernoulli(p.detach(), generator=self._generator(p.device))
+        return p
+
+
+class MaskCBAM(nn.Module):
+    """Mask-guided CBAM at one pyramid level: masked avg/max channel attention -> spatial attention that also sees the
+    mask -> ``x + softplus(beta) * (refined - x)``.  Drop-in for the reference class of the same name."""
+
+    def __init__(self, channels: int, r: int = 16, spatial_k: int = 7, use_sigmoid_mask: bool = True,
+                 tiny_mask_thr: float = 1e-4, eps: float = 1e-6) -> None:
+        super().__init__()
+        assert r > 0 and channels > 0
+        self.C = channels
+        self.r = r
+        self.k = spatial_k if spatial_k % 2 == 1 else spatial_k + 1
+        self.use_sigmoid_mask = use_sigmoid_mask
+        self.tiny_thr = tiny_mask_thr
+        self.eps = eps
+        hidden = max(1, channels // r)
+        # containers only hold the parameters (same names/order/init as the reference); the math runs in the kernels
+        self.cam_mlp = nn.Sequential(nn.Linear(channels, hidden, bias=True), nn.ReLU(inplace=True),
+                                     nn.Linear(hidden, channels, bias=True))
+        self.sam_conv = nn.Conv2d(3, 1, kernel_size=self.k, padding=self.k // 2, bias=False)
+        self.beta = nn.Parameter(torch.zeros((), dtype=torch.float32))
+        if os.getenv("MGA_PROB_MODE", False):                                   # masked_cbam.py:67-78 (truthy for any string)
+            approach = os.getenv("MGA_PROB_APPROACH", "gumbel")
+            if approach not in _GATER_MODES:
+                raise ValueError(f"MGA_PROB_APPROACH must be one of {set(_GATER_MODES)}, got {approach}")
+            self.gater = ProbMaskGater(mode=approach, tau=1.0, p_min=0.0, threshold=0.5, seed=None)
+
+    # ------------------------------------------------------------------ reference surface
+    @property
+    def alpha(self) -> torch.Tensor:
+        return F.softplus(self.beta)
+
+    @property
+    def hidden(self) -> int:
+        return self.cam_mlp[0].out_features
+
+    def block_config(self) -> BlockConfig:
+        return BlockConfig(hidden=self.hidden, k=self.k, use_sigmoid_mask=bool(self.use_sigmoid_mask),
+                           tiny_thr=float(self.tiny_thr), eps=float(self.eps))
+
+    def block_params(self):
+        return (self.cam_mlp[0].weight, self.cam_mlp[0].bias, self.cam_mlp[2].weight, self.cam_mlp[2].bias,
+                self.sam_conv.weight, self.beta)
+
+    def forward(self, x: Union[torch.Tensor, Sequence[torch.Tensor]]) -> torch.Tensor:
+        if isinstance(x, (list, tuple)):
+            assert len(x) == 2, "MaskCBAM expects [feature, mask]"
+            feat, mask = x
+        else:
+            feat, mask = x, None
+        assert isinstance(feat, torch.Tensor) and feat.dim() == 4
+        if os.getenv("MGA_PROB_MODE", False) and mask is not None:              # masked_cbam.py:163-164
+            mask = self.gater(mask)
+        if feat.is_cuda:
+            params = tuple(p.float() if p.dtype != torch.float32 else p for p in self.block_params())
+            return mask_cbam(feat, mask, *params, self.block_config())
+        return _host_forward(feat, mask, self.block_params(), self.block_config())
+
+    def extra_repr(self) -> str:
+        return (f"channels={self.C}, r={self.r}, spatial_k={self.k}, use_sigmoid_mask={self.use_sigmoid_mask}, "
+                f"tiny_mask_thr={self.tiny_thr}, eps={self.eps}, alpha={self.alpha.item():.4f}")
+
+
+def _host_forward(x: torch.Tensor, mask: Optional[torch.Tensor], params, cfg: BlockConfig) -> torch.Tensor:
+    """Same mathematics in differentiable PyTorch ops for HOST tensors only (build-time stride probe, device='cpu' runs)."""
+    w1, b1, w2, b2, wsa, beta = params
+    B, Cc, H, W = x.shape
+    flat = x.flatten(2)                                                        # (B,C,N)
+    gap = flat.mean(dim=2)
+    if mask is None:
+        avg, mx = gap, flat.amax(dim=2)
+        plane = x.new_zeros(B, 1, H, W)
+    else:
+        m = mask.unsqueeze(1) if mask.dim() == 3 else mask
+        if tuple(m.shape) != (B, 1, H, W):
+            raise RuntimeError(f"mask shape {tuple(mask.shape)} does not match feature (B,1,H,W)=({B},1,{H},{W})")
+        s = (m.sigmoid() if cfg.use_sigmoid_mask else m).to(x.dtype)
+        sf = s.flatten(2)                                                      # (B,1,N)
+        total = sf.sum(dim=2)                                                  # (B,1)
+        use = (total / (H * W) >= cfg.tiny_thr).to(x.dtype)
+        mavg = (flat * sf).sum(dim=2) / total.clamp_min(cfg.eps)
+        avg = mavg * use + gap * (1.0 - use)
+        low = torch.finfo(x.dtype).min
+        mmax = flat.masked_fill(~(sf > 0.5), low).amax(dim=2)
+        mx = torch.where(torch.isclose(mmax, torch.full_like(mmax, low)), gap, mmax)
+        plane = s
+    gate = lambda d: F.linear(F.relu(F.linear(d, w1.to(d.dtype), b1.to(d.dtype))), w2.to(d.dtype), b2.to(d.dtype))
+    ca = torch.sigmoid(gate(avg) + gate(mx)).view(B, Cc, 1, 1)
+    u = x * ca
+    planes = torch.cat([u.amax(dim=1, keepdim=True), u.mean(dim=1, keepdim=True), plane], dim=1)
+    sa = torch.sigmoid(F.conv2d(planes, wsa.to(x.dtype), padding=cfg.k // 2))
+    return x + F.softplus(beta).to(x.dtype) * (u * sa - x)

@@ -1,0 +1,281 @@
+"""GPU parity tests (-m gpu): the HIP path behind the C ABI vs the oracle, the golden vectors from the reference, and
+size-independent properties at BASELINE.json's full sizes.  Tolerance: 1e-4 relative (fp32), the bar north_star states;
+index outputs (arg-max positions / channels, nearest-resize) must be bit-exact."""
+import os
+
+import pytest
+import torch
+
+from conftest import checksum, golden_case_names, load_golden, rel_err, synth
+from oracle import maskcbam_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4          # north_star: within 1e-4 relative fp32
+GRADS = ("gx", "gmask", "gw1", "gb1", "gw2", "gb2", "gwsa", "gbeta")
+
+
+@pytest.fixture(scope="module")
+def F():
+    import mga_yolo_amd.functional as Fn
+    from mga_yolo_amd import _lib
+    _lib.load()                      # fail loudly if libmgacbam.so is missing
+    return Fn
+
+
+def _cfg(F, d):
+    m = d["meta"]
+    hidden = d["params"]["cam_mlp.0.weight"].shape[0]
+    return F.BlockConfig(hidden=hidden, k=m["k"], use_sigmoid_mask=m["use_sigmoid_mask"], tiny_thr=m["tiny_thr"], eps=m["eps"])
+
+
+def _params_dev(d, requires_grad=False):
+    keys = ("cam_mlp.0.weight", "cam_mlp.0.bias", "cam_mlp.2.weight", "cam_mlp.2.bias", "sam_conv.weight", "beta")
+    return [d["params"][k].cuda().requires_grad_(requires_grad) for k in keys]
+
+
+def _run_gpu(F, d):
+    x = d["x"].cuda().requires_grad_(True)
+    mask = None if d["mask"] is None else d["mask"].cuda().requires_grad_(True)
+    ps = _params_dev(d, True)
+    y = F.mask_cbam(x, mask, *ps, _cfg(F, d))
+    y.backward(d["gy"].cuda())
+    g = dict(gx=x.grad, gmask=None if mask is None else mask.grad, gw1=ps[0].grad, gb1=ps[1].grad, gw2=ps[2].grad,
+             gb2=ps[3].grad, gwsa=ps[4].grad, gbeta=ps[5].grad)
+    return y.detach(), g
+
+
+@pytest.mark.parametrize("name", golden_case_names())
+def test_forward_stages_vs_oracle(F, name):
+    """Every statistic the forward kernels save, compared with the oracle's intermediates: localises a failure to a kernel."""
+    d = load_golden(name)
+    p = O.Params.from_state_dict(d["params"])
+    ocfg = O.Config(use_sigmoid_mask=d["meta"]["use_sigmoid_mask"], tiny_thr=d["meta"]["tiny_thr"], eps=d["meta"]["eps"])
+    y_o, c = O.forward(d["x"], d["mask"], p, ocfg)
+    y, v = F.forward_with_ctx(d["x"].cuda(), None if d["mask"] is None else d["mask"].cuda(), _params_dev(d), _cfg(F, d))
+    torch.cuda.synchronize()
+    B, C, H, W = d["x"].shape
+    report = []
+
+    def close(name_, got, want, tol=TOL):
+        e = rel_err(got, want)
+        if not e < tol:
+            report.append(f"{name_}: rel_err={e:.3e}")
+
+    def same(name_, got, want):
+        if not torch.equal(got.cpu().long(), want.long()):
+            report.append(f"{name_}: {int((got.cpu().long() != want.long()).sum())} mismatching indices")
+
+    if d["mask"] is not None:
+        close("S", v["S"], c.S); close("use", v["use"], c.use); close("den", v["den"], c.den)
+        close("mavg", v["mavg"], c.mavg)
+    close("avg", v["avg"], c.avg); close("mx", v["mx"], c.mx)
+    same("valid", v["valid"], c.valid.long())
+    same("amax[valid]", v["amax"].cpu() * c.valid.long(), c.amax * c.valid.long())
+    close("h_avg", v["h_avg"], c.h_avg); close("h_mx", v["h_mx"], c.h_mx); close("ca", v["ca"], c.ca)
+    close("planes", v["planes"], c.planes.reshape(B, 3, H * W))
+    if name not in ("stride_probe",):            # all-zero input: every channel ties; first index still required
+        pass
+    same("cidx", v["cidx"], c.cidx)
+    close("sa", v["sa"], c.sa)
+    close("y", y, y_o)
+    close("y_vs_reference", y, d["out"]["y"])
+    assert not report, f"{name}: " + "; ".join(report)
+
+
+@pytest.mark.parametrize("name", golden_case_names())
+def test_fwd_bwd_vs_reference_golden(F, name):
+    d = load_golden(name)
+    y, g = _run_gpu(F, d)
+    torch.cuda.synchronize()
+    report = []
+    e = rel_err(y, d["out"]["y"])
+    if not e < TOL:
+        report.append(f"y {e:.3e}")
+    for k in GRADS:
+        if k == "gmask" and d["mask"] is None:
+            assert g[k] is None
+            continue
+        assert g[k].shape == d["out"][k].shape, k
+        e = rel_err(g[k], d["out"][k])
+        if not e < TOL:
+            report.append(f"{k} {e:.3e}")
+    assert not report, f"{name}: " + "; ".join(report)
+
+
+@pytest.mark.parametrize("name", ["cfg1_p3", "cfg1_p4", "cfg1_p5", "cfg2_p3", "cfg2_p4", "cfg2_p5", "survey_A1", "survey_nomask"])
+def test_full_size_checksums_vs_reference(F, checksums, name):
+    """BASELINE.json configs 1 and 2 (YOLOv8n, B=2 and B=32, 640x640): checksums of y and every gradient against the
+    values the reference itself produced (tests/golden/checksums.json)."""
+    ref = checksums["big"][name]
+    B, C, H, W = ref["shape"]
+    x, mask, gy = synth(B, C, H, W, mask_kind=ref["mask_kind"])
+    if ref["recipe"] == "ysum":
+        gy = torch.ones_like(x)
+    p = O.Params.default_init(C)
+    d = dict(x=x, mask=mask, gy=gy, params={"cam_mlp.0.weight": p.w1, "cam_mlp.0.bias": p.b1, "cam_mlp.2.weight": p.w2,
+                                            "cam_mlp.2.bias": p.b2, "sam_conv.weight": p.wsa, "beta": p.beta},
+             meta=dict(k=7, use_sigmoid_mask=True, tiny_thr=1e-4, eps=1e-6))
+    y, g = _run_gpu(F, d)
+    got = dict(y=y, **{k: v for k, v in g.items() if v is not None})
+    report = []
+    for k, v in got.items():
+        c = checksum(v)
+        scale = ref[k]["abs"] + 1e-12
+        for f in ("sum", "wsum", "abs"):
+            if not abs(c[f] - ref[k][f]) <= TOL * scale:
+                report.append(f"{k}.{f}: got {c[f]:.6f} want {ref[k][f]:.6f}")
+    assert not report, f"{name}: " + "; ".join(report)
+
+
+@pytest.mark.parametrize("shape,mask_kind", [((32, 64, 80, 80), "sparse"), ((32, 128, 40, 40), "randn"), ((32, 256, 20, 20), "sparse"),
+                                             ((4, 192, 40, 40), "mixed"), ((2, 384, 20, 20), "randn"), ((3, 48, 17, 17), "mixed")])
+def test_full_size_vs_oracle_live(F, shape, mask_kind):
+    """Same seeded inputs through the oracle (CPU) and the HIP path, element-wise, at config-2 sizes and the odd shapes."""
+    B, C, H, W = shape
+    x, mask, gy = synth(B, C, H, W, seed=77, mask_kind=mask_kind)
+    p = O.Params.default_init(C, seed=3)
+    p.beta.fill_(0.3)
+    y_o, ctx = O.forward(x, mask, p)
+    g_o = O.backward(gy, x, mask, p, O.Config(), ctx)
+    d = dict(x=x, mask=mask, gy=gy, params={"cam_mlp.0.weight": p.w1, "cam_mlp.0.bias": p.b1, "cam_mlp.2.weight": p.w2,
+                                            "cam_mlp.2.bias": p.b2, "sam_conv.weight": p.wsa, "beta": p.beta},
+             meta=dict(k=7, use_sigmoid_mask=True, tiny_thr=1e-4, eps=1e-6))
+    y, g = _run_gpu(F, d)
+    report = []
+    if not rel_err(y, y_o) < TOL:
+        report.append(f"y {rel_err(y, y_o):.3e}")
+    for k in GRADS:
+        if g_o[k] is None:
+            continue
+        e = rel_err(g[k], g_o[k])
+        if not e < TOL:
+            report.append(f"{k} {e:.3e}")
+    assert not report, "; ".join(report)
+
+
+def test_pyramid_call_equals_per_level_calls(F):
+    shapes = [(4, 64, 40, 40), (4, 128, 20, 20), (4, 256, 10, 10)]
+    lv, single = [], []
+    for i, (B, C, H, W) in enumerate(shapes):
+        x, mask, gy = synth(B, C, H, W, seed=10 + i)
+        p = O.Params.default_init(C, seed=i)
+        ps = [t.cuda() for t in (p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta)]
+        cfg = F.BlockConfig(hidden=p.w1.shape[0])
+        lv.append((x.cuda(), mask.cuda(), ps, cfg))
+        single.append(F.mask_cbam(x.cuda(), mask.cuda(), *ps, cfg))
+    outs = F.mask_cbam_pyramid(lv)
+    for a, b in zip(outs, single):
+        assert torch.equal(a, b)
+
+
+def test_bitwise_reproducible_and_batch_independent(F):
+    """Two-stage reductions, no float atomics: identical bits run to run; a sample's result does not depend on its batch."""
+    B, C, H, W = 8, 64, 40, 40
+    x, mask, gy = synth(B, C, H, W, seed=5, mask_kind="mixed")
+    p = O.Params.default_init(C)
+    base = dict(x=x, mask=mask, gy=gy, params={"cam_mlp.0.weight": p.w1, "cam_mlp.0.bias": p.b1, "cam_mlp.2.weight": p.w2,
+                                               "cam_mlp.2.bias": p.b2, "sam_conv.weight": p.wsa, "beta": p.beta},
+                meta=dict(k=7, use_sigmoid_mask=True, tiny_thr=1e-4, eps=1e-6))
+    y1, g1 = _run_gpu(F, base)
+    y2, g2 = _run_gpu(F, base)
+    assert torch.equal(y1, y2) and all(torch.equal(g1[k], g2[k]) for k in GRADS)
+    sub = dict(base, x=x[2:3], mask=mask[2:3], gy=gy[2:3])
+    ys, gs = _run_gpu(F, sub)
+    assert rel_err(ys, y1[2:3]) < 1e-6 and rel_err(gs["gx"], g1["gx"][2:3]) < 1e-6 and rel_err(gs["gmask"], g1["gmask"][2:3]) < 1e-6
+
+
+def test_backward_is_linear_in_gy(F):
+    """Property at config-2 size: gradients are linear in the upstream gradient (no oracle needed)."""
+    B, C, H, W = 32, 64, 80, 80
+    x, mask, gy = synth(B, C, H, W, seed=9, mask_kind="sparse")
+    p = O.Params.default_init(C)
+    mk = lambda g_: dict(x=x, mask=mask, gy=g_, params={"cam_mlp.0.weight": p.w1, "cam_mlp.0.bias": p.b1, "cam_mlp.2.weight": p.w2,
+                                                         "cam_mlp.2.bias": p.b2, "sam_conv.weight": p.wsa, "beta": p.beta},
+                         meta=dict(k=7, use_sigmoid_mask=True, tiny_thr=1e-4, eps=1e-6))
+    _, g1 = _run_gpu(F, mk(gy))
+    _, g2 = _run_gpu(F, mk(-2.5 * gy))
+    for k in GRADS:
+        assert rel_err(g2[k], -2.5 * g1[k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("env", [dict(MGACBAM_POOL_TX="16", MGACBAM_POOL_CPT="1", MGACBAM_CHAN_TX="16", MGACBAM_APPLY_TX="32", MGACBAM_APPLY_CPT="4"),
+                                 dict(MGACBAM_POOL_TX="64", MGACBAM_POOL_CPT="4", MGACBAM_CHAN_TX="64", MGACBAM_APPLY_TX="256", MGACBAM_APPLY_CPT="1"),
+                                 dict(MGACBAM_POOL_TX="128", MGACBAM_POOL_CPT="2", MGACBAM_CHAN_TX="32", MGACBAM_APPLY_TX="128", MGACBAM_APPLY_CPT="2"),
+                                 dict(MGACBAM_POOL_TX="256", MGACBAM_POOL_CPT="4", MGACBAM_CHAN_TX="8", MGACBAM_APPLY_TX="8", MGACBAM_APPLY_CPT="2"),
+                                 dict(MGACBAM_POOL_TX="1", MGACBAM_POOL_CPT="1", MGACBAM_CHAN_TX="1", MGACBAM_APPLY_TX="2", MGACBAM_APPLY_CPT="1")])
+def test_every_launch_geometry_gives_the_same_answer(F, env, monkeypatch):
+    """The launch-geometry hooks (rows x lanes, channels per thread) must not change results beyond rounding."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name in ("base", "mixed_batch", "odd17_c48", "hidden1_nonsq", "nomask"):
+        d = load_golden(name)
+        y, g = _run_gpu(F, d)
+        assert rel_err(y, d["out"]["y"]) < TOL, name
+        for k in GRADS:
+            if g[k] is not None:
+                assert rel_err(g[k], d["out"][k]) < TOL, (name, k)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+def test_half_precision_io(F, dtype, tol):
+    """fp16 / bf16 features and gradients with fp32 accumulation, against the fp32 oracle on the rounded inputs."""
+    B, C, H, W = 4, 64, 20, 20
+    x, mask, gy = synth(B, C, H, W, seed=21)
+    x, gy = x.to(dtype).float(), gy.to(dtype).float()
+    p = O.Params.default_init(C)
+    y_o, ctx = O.forward(x, mask, p)
+    g_o = O.backward(gy, x, mask, p, O.Config(), ctx)
+    xd = x.cuda().to(dtype).requires_grad_(True)
+    md = mask.cuda().requires_grad_(True)
+    ps = [t.cuda().requires_grad_(True) for t in (p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta)]
+    y = F.mask_cbam(xd, md, *ps, F.BlockConfig(hidden=p.w1.shape[0]))
+    assert y.dtype == dtype
+    y.backward(gy.cuda().to(dtype))
+    assert xd.grad.dtype == dtype and md.grad.dtype == torch.float32
+    assert rel_err(y.float(), y_o) < tol
+    assert rel_err(xd.grad.float(), g_o["gx"]) < tol
+    assert rel_err(md.grad, g_o["gmask"]) < tol
+    assert rel_err(ps[0].grad, g_o["gw1"]) < tol and rel_err(ps[5].grad, g_o["gbeta"]) < tol
+
+
+@pytest.mark.parametrize("out_hw,in_hw", [((80, 80), (640, 640)), ((40, 40), (640, 640)), ((20, 20), (640, 640)),
+                                          ((68, 68), (544, 544)), ((17, 17), (544, 544)), ((7, 13), (10, 29)), ((33, 5), (100, 3))])
+def test_nearest_resize_bit_exact(F, out_hw, in_hw):
+    import torch.nn.functional as Fnn
+    g = torch.Generator().manual_seed(3)
+    src = (torch.rand(2, 1, *in_hw, generator=g) > 0.5).float() + torch.rand(2, 1, *in_hw, generator=g)
+    want = Fnn.interpolate(src, size=out_hw, mode="nearest")
+    got = F.resize_nearest(src.cuda(), *out_hw).cpu()
+    assert torch.equal(got, want)
+    assert torch.equal(got, O.nearest_resize(src, *out_hw))
+
+
+def test_module_on_device_matches_module_on_host():
+    from mga_yolo_amd import MaskCBAM
+    torch.manual_seed(0)
+    m = MaskCBAM(64)
+    x, mask, gy = synth(2, 64, 20, 20)
+    xh, mh = x.clone().requires_grad_(True), mask.clone().requires_grad_(True)
+    yh = m([xh, mh]); yh.backward(gy)
+    gh = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad(); m.cuda()
+    xd, md = x.cuda().requires_grad_(True), mask.cuda().requires_grad_(True)
+    yd = m([xd, md]); yd.backward(gy.cuda())
+    assert rel_err(yd, yh) < TOL and rel_err(xd.grad, xh.grad) < TOL and rel_err(md.grad, mh.grad) < TOL
+    for n, p in m.named_parameters():
+        assert rel_err(p.grad, gh[n]) < TOL, n
+    # plain tensor input = no mask; forward hooks see a plain tensor
+    seen = []
+    h = m.register_forward_hook(lambda mod, inp, out: seen.append(type(out)))
+    out = m(x.cuda())
+    h.remove()
+    assert seen == [torch.Tensor] and out.shape == x.shape
+
+
+def test_native_library_is_loaded_in_this_process():
+    """The round-end check records which .so files the test process loaded: make sure ours is one of them."""
+    from mga_yolo_amd import _lib
+    _lib.load()
+    maps = open("/proc/self/maps").read()
+    assert "libmgacbam.so" in maps
