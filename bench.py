@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's headline benchmark on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2]
+
+A *step* is one pass of the hot path over one batch: MaskCBAM forward + backward at P3, P4 and P5 (YOLOv8n channel
+widths, 640x640 input -> 80/40/20 px feature maps, batch 32 per GPU, fp32, random masks = BASELINE.json configs[1]),
+followed -- when N > 1 -- by the data-parallel exchange of the block's parameter gradients (one flat bucket, RCCL
+all-reduce, overlapped with the input-gradient kernel).  Inputs are synthetic and already resident in HBM when timing
+starts.  For N > 1 the driver starts one process per GPU with torch.distributed.run; RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* are read from the environment.  Rank 0 prints ONE JSON line:
+
+  value        images/s over all N GPUs = N * batch / step time (max over ranks)             "scaling": "weak"
+  roofline     the dominant kernel: algorithmic bytes per launch / its mean duration (events on the launch stream)
+  kernels      the same for every HBM-bound kernel, plus the whole step against SURVEY 8d's 8*E*4 bytes
+  cpu_baseline the oracle's eager-op form (same op sequence as the reference's PyTorch-CPU path) timed on this
+               box's host cores on a bounded sample (rank 0, N = 1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable)
+
+WORKLOADS = {
+    # name: (description, per-GPU batch, [(C, H, W) for P3, P4, P5])
+    "cfg2": ("YOLOv8n+MGA-CBAM P3/P4/P5, 32x640x640 synthetic per GPU, fp32 (BASELINE.json configs[1])", 32,
+             [(64, 80, 80), (128, 40, 40), (256, 20, 20)]),
+    "cfg1": ("YOLOv8n+MGA-CBAM P3/P4/P5, 2x640x640 (BASELINE.json configs[0] shapes)", 2,
+             [(64, 80, 80), (128, 40, 40), (256, 20, 20)]),
+    "cfg3": ("YOLOv8s+MGA-CBAM P3/P4/P5, 32x640x640 per GPU (BASELINE.json configs[2] shapes)", 32,
+             [(128, 80, 80), (256, 40, 40), (512, 20, 20)]),
+    "cfg4": ("YOLOv8m+MGA-CBAM P3/P4/P5, 8x1280x1280 per GPU (BASELINE.json configs[3] shapes, > Infinity Cache)", 8,
+             [(256, 160, 160), (512, 80, 80), (512, 40, 40)]),
+}
+
+# algorithmic bytes of each HBM-bound kernel in units of E*w (feature-sized tensors it must read or write once)
+FWD_KERNEL_E = {"pool": 1, "chan": 1, "apply": 2}
+BWD_KERNEL_E = {"reduce1": 2, "reduce2": 1, "apply": 3}
+KERNEL_SYMBOL = {"fwd.pool": "k_pool", "fwd.chan": "k_chan", "fwd.apply": "k_apply", "fwd.mlp": "k_mlp_fwd",
+                 "fwd.conv": "k_conv_fwd", "bwd.reduce1": "k_bwd_reduce1", "bwd.reduce2": "k_bwd_reduce2",
+                 "bwd.apply": "k_bwd_apply", "bwd.convT": "k_bwd_convT", "bwd.mlp": "k_bwd_mlp", "bwd.finalize": "k_bwd_finalize"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying hipGraphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the bounded CPU-baseline sample")
+    ap.add_argument("--kernel-reps", type=int, default=30)
+    return ap.parse_args()
+
+
+def relaunch_distributed(args):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU with torch.distributed.run (child process)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def make_plan(workload, device, seed):
+    import torch
+    from mga_yolo_amd import MaskCBAM
+    from mga_yolo_amd.plan import PyramidPlan
+    desc, batch, lv = WORKLOADS[workload]
+    shapes, params, cfgs = [], [], []
+    for (C, H, W) in lv:
+        torch.manual_seed(0)                                   # default init, seed 0
+        m = MaskCBAM(C)
+        shapes.append((batch, C, H, W)); params.append(m.block_params()); cfgs.append(m.block_config())
+    plan = PyramidPlan(shapes, params, cfgs, dtype=torch.float32, device=device, with_mask=True, want_gmask=True)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    for l, (B, C, H, W) in enumerate(shapes):                  # SiLU-shaped features, sparse (vessel-like) masks, N(0,1) upstream grads
+        plan.x[l].copy_(torch.nn.functional.silu(torch.randn(B, C, H, W, generator=g)))
+        plan.mask[l].copy_(torch.randn(B, 1, H, W, generator=g) - 2.0)
+        plan.gy[l].copy_(torch.randn(B, C, H, W, generator=g))
+    return plan, desc, batch
+
+
+def time_kernels(plan, reps):
+    """Mean duration of every kernel group (all levels of one stage), measured with events on the launch stream."""
+    import torch
+    from mga_yolo_amd import _lib
+    out = {}
+    todo = [("fwd." + k, plan.forward, v) for k, v in _lib.FWD_STAGES.items()] + \
+           [("bwd." + k, plan.backward, v) for k, v in _lib.BWD_STAGES.items()]
+    for name, fn, mask in todo:
+        for _ in range(3):
+            fn(mask)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn(mask)
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = e0.elapsed_time(e1) * 1e3 / reps            # us per stage (n_levels launches)
+    return out
+
+
+def cpu_baseline(workload, seconds):
+    """The oracle's eager-op form = the reference's PyTorch-CPU op sequence, fwd+bwd over the three levels."""
+    import torch
+    from oracle import maskcbam_oracle as O
+    desc, batch, lv = WORKLOADS[workload]
+    cores = min(16, os.cpu_count() or 1)                         # the box's CPU share for one GPU
+    torch.set_num_threads(cores)
+    sample_batch = batch
+    g = torch.Generator().manual_seed(1234)
+    data = []
+    for (C, H, W) in lv:
+        x = torch.nn.functional.silu(torch.randn(sample_batch, C, H, W, generator=g))
+        mask = torch.randn(sample_batch, 1, H, W, generator=g) - 2.0
+        gy = torch.randn(sample_batch, C, H, W, generator=g)
+        data.append((x, mask, gy, O.Params.default_init(C)))
+    cfg = O.Config()
+
+    def one():
+        for x, mask, gy, p in data:
+            O.reference_form_step(x, mask, p, cfg, gy)
+    one()                                                        # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds or n >= 50:
+            break
+    return dict(value=round(sample_batch * n / el, 2), unit="images/s", cores=cores, kind="port",
+                sample=f"{n} fwd+bwd steps of the oracle's eager-op form (oracle/maskcbam_oracle.py:reference_form_step) "
+                       f"over P3+P4+P5 at batch {sample_batch}, torch CPU fp32, {cores} threads, {el:.1f} s")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        sys.exit(relaunch_distributed(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import torch.distributed as dist
+    from mga_yolo_amd import _lib
+    from mga_yolo_amd.dp import GradExchange
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # "nccl" is RCCL on ROCm
+
+    plan, desc, batch = make_plan(args.workload, device, seed=1234 + rank)
+    exchange = GradExchange(plan.grad_bucket)                    # no-op when world == 1
+
+    def part1():
+        plan.forward()
+        plan.backward_params()
+
+    def part2():
+        plan.backward_inputs()
+
+    if args.no_graph:
+        run1, run2 = part1, part2
+    else:
+        g1, g2 = plan.capture(part1), plan.capture(part2)
+        run1, run2 = g1.replay, g2.replay
+
+    def step():
+        run1()                  # forward; backward up to the parameter gradients
+        exchange.start()        # N > 1: all-reduce of the flat gradient bucket on a side stream ...
+        run2()                  # ... overlapped with the input-gradient kernel
+        exchange.finish()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * batch * args.steps / elapsed
+
+    # ---- per-kernel durations on this GPU, isolated launches on the same stream -------------------------------
+    kt = time_kernels(plan, args.kernel_reps)
+    E = plan.elements()
+    w = 4
+    kernels = {}
+    for name, us in kt.items():
+        side, k = name.split(".")
+        mult = (FWD_KERNEL_E if side == "fwd" else BWD_KERNEL_E).get(k)
+        ent = dict(us=round(us, 2), launches=plan.n, symbol=KERNEL_SYMBOL[name])
+        if mult:
+            ent["alg_bytes"] = mult * E * w
+            ent["GBps"] = round(mult * E * w / us / 1e3, 1)
+        kernels[name] = ent
+    dom = max((n for n in kernels if "alg_bytes" in kernels[n]), key=lambda n: kernels[n]["us"])
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")   # PMC-derived HBM bytes (collected with rocprofv3, see profiles/)
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload, {}).get(KERNEL_SYMBOL[dom])
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", kernel=KERNEL_SYMBOL[dom], stage=dom, achieved=kernels[dom]["GBps"], peak=HBM_PEAK_GBPS, unit="GB/s",
+                    frac=round(kernels[dom]["GBps"] / HBM_PEAK_GBPS, 4), traffic=traffic,
+                    alg_bytes_per_launch_group=kernels[dom]["alg_bytes"], us=kernels[dom]["us"],
+                    note="one launch group = this stage for P3+P4+P5; duration = mean over back-to-back launches between two events on the launch stream")
+    step_alg = 8 * E * w                                           # forward 3*E*w + backward 5*E*w
+    step_roof = dict(alg_bytes=step_alg, GBps=round(step_alg / (ms_per_step * 1e-3) / 1e9, 1),
+                     frac=round(step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                     sum_kernel_us=round(sum(kt.values()), 1))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload, args.cpu_seconds)
+
+    if rank == 0:
+        line = dict(metric="images/s (MaskCBAM fwd+bwd step at P3/P4/P5, YOLOv8n 640x640)", value=round(value, 1), unit="images/s",
+                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
+                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                    config=dict(workload=desc, batch_per_gpu=batch, global_batch=batch * world,
+                                levels=[list(s) for s in plan.shapes], parallelism=f"dp{world}",
+                                launch="eager" if args.no_graph else "hipGraph replay (2 graphs/step)",
+                                grad_exchange=None if world == 1 else f"RCCL all-reduce of one {plan.grad_bucket.numel() * 4} B bucket, overlapped with k_bwd_apply"),
+                    roofline=roofline, step_roofline=step_roof, kernels=kernels, cpu_baseline=cpu,
+                    lib=_lib.load().mgacbam_build_info().decode())
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -121,6 +121,34 @@ int mgacbam_ctx_layout(int B, int C, int H, int W, int hidden, mgacbam_ctx_layou
 int mgacbam_forward(const mgacbam_fwd_level_t* levels, int n_levels, void* stream);
 int mgacbam_backward(const mgacbam_bwd_level_t* levels, int n_levels, void* stream);
 
+/* The same work split into its kernels ("stages"), in dependency order.  mgacbam_forward == all forward stages,
+ * mgacbam_backward == all backward stages.  Uses:
+ *   - data-parallel training: enqueue MGACBAM_BWD_PARAMS (everything the parameter gradients need), start the
+ *     gradient all-reduce on another stream, then enqueue MGACBAM_BWD_INPUTS (gx, gmask) so the exchange overlaps it;
+ *   - measurement: time one kernel alone with events on `stream` (bench.py roofline).
+ * A later stage reads what earlier stages left in ctx / scratch, so both buffers must be kept between calls. */
+enum {
+  MGACBAM_FWD_POOL = 1,      /* masked avg/max pooling over H*W          reads x                    */
+  MGACBAM_FWD_MLP = 2,       /* shared MLP + channel gate                tiny                       */
+  MGACBAM_FWD_CHAN = 4,      /* channel max/mean planes                  reads x                    */
+  MGACBAM_FWD_CONV = 8,      /* k x k conv + spatial gate                tiny                       */
+  MGACBAM_FWD_APPLY = 16,    /* y = x + alpha (x ca sa - x)              reads x, writes y          */
+  MGACBAM_FWD_ALL = 31
+};
+enum {
+  MGACBAM_BWD_REDUCE1 = 1,   /* sums of gy*x over H*W and over C         reads x, gy                */
+  MGACBAM_BWD_CONVT = 2,     /* transposed conv + dWsa partials          tiny                       */
+  MGACBAM_BWD_REDUCE2 = 4,   /* rest of dL/dca, dL/dz                    reads x                    */
+  MGACBAM_BWD_MLP = 8,       /* shared-MLP backward                      tiny                       */
+  MGACBAM_BWD_FINALIZE = 16, /* dW1 db1 dW2 db2 dWsa dbeta               tiny                       */
+  MGACBAM_BWD_APPLY = 32,    /* gx (+ gmask)                             reads gy (+x), writes gx   */
+  MGACBAM_BWD_PARAMS = 31,   /* stages the parameter gradients depend on */
+  MGACBAM_BWD_INPUTS = 32,   /* stages only the input gradients depend on */
+  MGACBAM_BWD_ALL = 63
+};
+int mgacbam_forward_stages(const mgacbam_fwd_level_t* levels, int n_levels, int stages, void* stream);
+int mgacbam_backward_stages(const mgacbam_bwd_level_t* levels, int n_levels, int stages, void* stream);
+
 /* Nearest-neighbour resize of (n_planes, in_h, in_w) fp32 planes to (n_planes, out_h, out_w): the integer
  * index path src = min(floor(dst * in/out), in-1) of mga_yolo/nn/losses/segmentation.py:103-110
  * (F.interpolate(mode="nearest")).  Bit-exact with the reference by construction (pure gather). */

@@ -11,6 +11,10 @@ LIB_PATH = os.path.join(_PKG, "libmgacbam.so")
 ABI_VERSION = 1
 MAX_LEVELS = 8
 F32, F16, BF16 = 0, 1, 2
+# stage bit masks (include/mgacbam.h)
+FWD_STAGES = dict(pool=1, mlp=2, chan=4, conv=8, apply=16)
+BWD_STAGES = dict(reduce1=1, convT=2, reduce2=4, mlp=8, finalize=16, apply=32)
+FWD_ALL, BWD_PARAMS, BWD_INPUTS, BWD_ALL = 31, 31, 32, 63
 
 _c_float_p = C.POINTER(C.c_float)
 
@@ -54,6 +58,8 @@ SYMBOLS = {
     "mgacbam_ctx_layout": (C.c_int, [C.c_int] * 5 + [C.POINTER(CtxLayout)]),
     "mgacbam_forward": (C.c_int, [C.POINTER(FwdLevel), C.c_int, C.c_void_p]),
     "mgacbam_backward": (C.c_int, [C.POINTER(BwdLevel), C.c_int, C.c_void_p]),
+    "mgacbam_forward_stages": (C.c_int, [C.POINTER(FwdLevel), C.c_int, C.c_int, C.c_void_p]),
+    "mgacbam_backward_stages": (C.c_int, [C.POINTER(BwdLevel), C.c_int, C.c_int, C.c_void_p]),
     "mgacbam_resize_nearest": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
 }
 

@@ -205,7 +205,7 @@ static int check_params(const mgacbam_params_t& p) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-static int forward_level(const mgacbam_fwd_level_t& L, hipStream_t st) {
+static int forward_level(const mgacbam_fwd_level_t& L, int stages, hipStream_t st) {
   if (!L.x || !L.y || !L.ctx) return fail(MGACBAM_E_NULL, "forward: x / y / ctx is NULL");
   if (int e = check_params(L.p)) return e;
   if (int e = check_shape(L.B, L.C, L.H, L.W, L.p.hidden, L.p.k)) return e;
@@ -225,7 +225,7 @@ static int forward_level(const mgacbam_fwd_level_t& L, hipStream_t st) {
   const int nv = g.HW / VEC;
   const bool has_mask = L.mask != nullptr;
 
-  {  // 1. pooling
+  if (stages & MGACBAM_FWD_POOL) {  // 1. pooling
     const int TY = kBlock / A.t.pool_tx, CPB = TY * A.t.pool_cpt;
     const int grid = g.B * ((g.C + CPB - 1) / CPB);
 #define CALL_POOL2(CPTV) if (has_mask) LAUNCH((k_pool<TT, VV, CPTV, true>), grid, 0, st, A); else LAUNCH((k_pool<TT, VV, CPTV, false>), grid, 0, st, A)
@@ -235,19 +235,19 @@ static int forward_level(const mgacbam_fwd_level_t& L, hipStream_t st) {
 #undef CALL_POOL2
     if (int e = launch_status("k_pool")) return e;
   }
-  {  // 2. shared MLP + channel gate
+  if (stages & MGACBAM_FWD_MLP) {  // 2. shared MLP + channel gate
     const size_t smem = (2 * static_cast<size_t>(g.C) + 2 * g.hidden) * sizeof(float);
     LAUNCH(k_mlp_fwd, g.B, smem, st, A);
     if (int e = launch_status("k_mlp_fwd")) return e;
   }
-  {  // 3. channel max / mean planes
+  if (stages & MGACBAM_FWD_CHAN) {  // 3. channel max / mean planes
     const int grid = g.B * ((nv + A.t.chan_tx - 1) / A.t.chan_tx);
 #define CALL_CHAN(Tt, Vv) LAUNCH((k_chan<Tt, Vv>), grid, 0, st, A)
     DISPATCH_T_VEC(L.dtype, VEC, CALL_CHAN);
 #undef CALL_CHAN
     if (int e = launch_status("k_chan")) return e;
   }
-  {  // 4. k x k conv + sigmoid
+  if (stages & MGACBAM_FWD_CONV) {  // 4. k x k conv + sigmoid
     const int grid = g.B * conv_tiles(A.t, g.H, g.W);
     const size_t smem = 3 * static_cast<size_t>(A.t.conv_th + g.k - 1) * (A.t.conv_twq * 4 + g.k - 1) * sizeof(float);
     switch (g.k) {
@@ -258,7 +258,7 @@ static int forward_level(const mgacbam_fwd_level_t& L, hipStream_t st) {
     }
     if (int e = launch_status("k_conv_fwd")) return e;
   }
-  {  // 5. apply both gates + alpha residual
+  if (stages & MGACBAM_FWD_APPLY) {  // 5. apply both gates + alpha residual
     const int TY = kBlock / A.t.apply_tx, CPB = TY * A.t.apply_cpt;
     const int grid = g.B * ((g.C + CPB - 1) / CPB);
 #define CALL_APPLY2(CPTV) LAUNCH((k_apply<TT, VV, CPTV>), grid, 0, st, A)
@@ -271,20 +271,23 @@ static int forward_level(const mgacbam_fwd_level_t& L, hipStream_t st) {
   return 0;
 }
 
-extern "C" int mgacbam_forward(const mgacbam_fwd_level_t* levels, int n_levels, void* stream) {
+extern "C" int mgacbam_forward_stages(const mgacbam_fwd_level_t* levels, int n_levels, int stages, void* stream) {
   if (!levels) return fail(MGACBAM_E_NULL, "levels is NULL");
   if (n_levels < 1 || n_levels > MGACBAM_MAX_LEVELS) return fail(MGACBAM_E_LEVELS, "n_levels=%d", n_levels);
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int l = 0; l < n_levels; ++l)
-    if (int e = forward_level(levels[l], st)) return e;
+    if (int e = forward_level(levels[l], stages, st)) return e;
   g_err[0] = 0;
   return 0;
+}
+extern "C" int mgacbam_forward(const mgacbam_fwd_level_t* levels, int n_levels, void* stream) {
+  return mgacbam_forward_stages(levels, n_levels, MGACBAM_FWD_ALL, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-static int backward_level(const mgacbam_bwd_level_t& L, hipStream_t st) {
+static int backward_level(const mgacbam_bwd_level_t& L, int stages, hipStream_t st) {
   if (!L.x || !L.gy || !L.ctx || !L.scratch || !L.gx) return fail(MGACBAM_E_NULL, "backward: x / gy / ctx / scratch / gx is NULL");
   if (!L.gw1 || !L.gb1 || !L.gw2 || !L.gb2 || !L.gwsa || !L.gbeta) return fail(MGACBAM_E_NULL, "backward: NULL parameter-gradient pointer");
   if (L.gmask && !L.mask) return fail(MGACBAM_E_NULL, "backward: gmask requested but mask is NULL");
@@ -317,14 +320,14 @@ static int backward_level(const mgacbam_bwd_level_t& L, hipStream_t st) {
   A.nconv = g.B * conv_tiles(A.t, g.H, g.W);
   const bool want_gmask = L.gmask != nullptr;
 
-  {  // 1. per-(b,c) and per-pixel reductions of gy*x
+  if (stages & MGACBAM_BWD_REDUCE1) {  // 1. per-(b,c) and per-pixel reductions of gy*x
     const int grid = g.B * A.nt;
 #define CALL_R1(Tt, Vv) LAUNCH((k_bwd_reduce1<Tt, Vv>), grid, 0, st, A)
     DISPATCH_T_VEC(L.dtype, VEC, CALL_R1);
 #undef CALL_R1
     if (int e = launch_status("k_bwd_reduce1")) return e;
   }
-  {  // 2. transposed conv + dWsa partials
+  if (stages & MGACBAM_BWD_CONVT) {  // 2. transposed conv + dWsa partials
     const size_t smem = 4 * static_cast<size_t>(A.t.conv_th + g.k - 1) * (A.t.conv_twq * 4 + g.k - 1) * sizeof(float);
     switch (g.k) {
       case 3: LAUNCH(k_bwd_convT<3>, A.nconv, smem, st, A); break;
@@ -334,7 +337,7 @@ static int backward_level(const mgacbam_bwd_level_t& L, hipStream_t st) {
     }
     if (int e = launch_status("k_bwd_convT")) return e;
   }
-  {  // 3. remaining part of g_ca (needs g_planes), g_z
+  if (stages & MGACBAM_BWD_REDUCE2) {  // 3. remaining part of g_ca (needs g_planes), g_z
     const int TY = kBlock / A.t.pool_tx, CPB = TY * A.t.pool_cpt;
     const int grid = g.B * ((g.C + CPB - 1) / CPB);
 #define CALL_R22(CPTV) LAUNCH((k_bwd_reduce2<TT, VV, CPTV>), grid, 0, st, A)
@@ -344,35 +347,38 @@ static int backward_level(const mgacbam_bwd_level_t& L, hipStream_t st) {
 #undef CALL_R22
     if (int e = launch_status("k_bwd_reduce2")) return e;
   }
-  {  // 4. shared-MLP backward
+  if (stages & MGACBAM_BWD_MLP) {  // 4. shared-MLP backward
     const size_t smem = (static_cast<size_t>(g.C) + 2 * g.hidden) * sizeof(float);
     LAUNCH(k_bwd_mlp, g.B, smem, st, A);
     if (int e = launch_status("k_bwd_mlp")) return e;
   }
-  {  // 5. gx (+ gmask)
+  if (stages & MGACBAM_BWD_FINALIZE) {  // 5. parameter gradients (do not depend on stage 6)
+    const int total = 2 * g.C * g.hidden + g.C + g.hidden + 3 * g.k * g.k;
+    const int grid = (total + kBlock - 1) / kBlock + 1;
+    LAUNCH(k_bwd_finalize, grid, 0, st, A);
+    if (int e = launch_status("k_bwd_finalize")) return e;
+  }
+  if (stages & MGACBAM_BWD_APPLY) {  // 6. gx (+ gmask)
     const int grid = g.B * A.nt;
 #define CALL_AP(Tt, Vv) if (want_gmask) LAUNCH((k_bwd_apply<Tt, Vv, true>), grid, 0, st, A); else LAUNCH((k_bwd_apply<Tt, Vv, false>), grid, 0, st, A)
     DISPATCH_T_VEC(L.dtype, VEC, CALL_AP);
 #undef CALL_AP
     if (int e = launch_status("k_bwd_apply")) return e;
   }
-  {  // 6. parameter gradients
-    const int total = 2 * g.C * g.hidden + g.C + g.hidden + 3 * g.k * g.k;
-    const int grid = (total + kBlock - 1) / kBlock + 1;
-    LAUNCH(k_bwd_finalize, grid, 0, st, A);
-    if (int e = launch_status("k_bwd_finalize")) return e;
-  }
   return 0;
 }
 
-extern "C" int mgacbam_backward(const mgacbam_bwd_level_t* levels, int n_levels, void* stream) {
+extern "C" int mgacbam_backward_stages(const mgacbam_bwd_level_t* levels, int n_levels, int stages, void* stream) {
   if (!levels) return fail(MGACBAM_E_NULL, "levels is NULL");
   if (n_levels < 1 || n_levels > MGACBAM_MAX_LEVELS) return fail(MGACBAM_E_LEVELS, "n_levels=%d", n_levels);
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int l = 0; l < n_levels; ++l)
-    if (int e = backward_level(levels[l], st)) return e;
+    if (int e = backward_level(levels[l], stages, st)) return e;
   g_err[0] = 0;
   return 0;
+}
+extern "C" int mgacbam_backward(const mgacbam_bwd_level_t* levels, int n_levels, void* stream) {
+  return mgacbam_backward_stages(levels, n_levels, MGACBAM_BWD_ALL, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

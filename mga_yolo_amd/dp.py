@@ -1,0 +1,64 @@
+"""Data-parallel gradient exchange for the block (one process per GPU, torch.distributed; backend "nccl" is RCCL over
+xGMI on ROCm, "gloo" on CPU for tests).
+
+The reference trains with DistributedDataParallel (U/engine/trainer.py:366-367): replicas, equal minibatch shards
+(``batch // world_size``, trainer.py:379), one bucketed all-reduce(mean) of parameter gradients per step.  The block has no
+cross-sample reduction, so its data path needs no collective; only its parameter gradients are exchanged:
+47 KB (YOLOv8n) to 302 KB (l) per step.  At that size an all-reduce over xGMI is latency-bound, not bandwidth-bound, so
+the one thing that matters is to START it early: ``PyramidPlan.backward_params()`` completes every parameter gradient
+before the large input-gradient kernel runs, ``GradExchange.start()`` then launches the all-reduce of ONE flat bucket on a
+side stream while ``backward_inputs()`` streams gx on the compute stream, and ``finish()`` joins the two.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def shard_batch(global_batch: int, world_size: int, rank: int) -> slice:
+    """Equal contiguous shards, as DistributedSampler / trainer.py:379 (global batch must divide evenly)."""
+    if global_batch % world_size:
+        raise ValueError(f"global batch {global_batch} is not divisible by world size {world_size}")
+    per = global_batch // world_size
+    return slice(rank * per, (rank + 1) * per)
+
+
+class GradExchange:
+    """All-reduce(mean) of one flat gradient bucket, overlapped with whatever the caller enqueues between
+    ``start()`` and ``finish()``."""
+
+    def __init__(self, bucket: torch.Tensor, group: Optional[dist.ProcessGroup] = None):
+        self.bucket = bucket
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.on_gpu = bucket.is_cuda
+        self.side = torch.cuda.Stream(bucket.device) if self.on_gpu else None
+        self._ready = torch.cuda.Event() if self.on_gpu else None
+        self._work = None
+
+    def start(self):
+        if self.world == 1:
+            return
+        if self.on_gpu:
+            cur = torch.cuda.current_stream(self.bucket.device)
+            self._ready.record(cur)                       # gradients complete at this point of the compute stream
+            self.side.wait_event(self._ready)
+            with torch.cuda.stream(self.side):
+                self._work = dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._work = dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        if self.world == 1:
+            return
+        if self.on_gpu:
+            with torch.cuda.stream(self.side):
+                self._work.wait()                         # orders the side stream after the collective
+                self.bucket.div_(self.world)              # DDP semantics: mean over replicas
+            torch.cuda.current_stream(self.bucket.device).wait_stream(self.side)
+        else:
+            self._work.wait()
+            self.bucket.div_(self.world)
+        self._work = None

@@ -1,0 +1,107 @@
+"""Static executor for the block over a feature pyramid: pre-allocated buffers, pre-built C-ABI level tables and
+hipGraph capture of the step.  This is the launch path for steady-state training loops on MI355X -- the YOLOv8n shapes
+are launch-latency bound (a full pass over the 52 MB P3 feature is ~10 us of HBM time), so the ~30 kernel launches of a
+step are recorded once and replayed, instead of being issued from Python every step.
+
+A ``PyramidPlan`` owns, per level: x, mask, y, gy, gx, gmask, ctx, scratch; and ONE flat fp32 bucket holding the parameter
+gradients of all levels (what data-parallel training all-reduces, see ``dp.py``).  ``forward`` / ``backward_params`` /
+``backward_inputs`` each make one library call on the current stream; ``backward_params`` finishes everything the
+parameter gradients depend on, so their all-reduce can overlap ``backward_inputs`` (gx, gmask).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .functional import BlockConfig, _DTYPES, _params_struct, ctx_views
+
+PARAM_NAMES = ("w1", "b1", "w2", "b2", "wsa", "beta")
+
+
+class PyramidPlan:
+    def __init__(self, shapes: Sequence[Tuple[int, int, int, int]], params: Sequence[Sequence[torch.Tensor]],
+                 cfgs: Sequence[BlockConfig], dtype: torch.dtype = torch.float32, device="cuda",
+                 with_mask: bool = True, want_gmask: bool = True):
+        assert len(shapes) == len(params) == len(cfgs) and 1 <= len(shapes) <= _lib.MAX_LEVELS
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.n = len(shapes)
+        self.shapes, self.cfgs, self.dtype = list(shapes), list(cfgs), dtype
+        self.params = [[p.detach().to(self.device, torch.float32).contiguous() for p in ps] for ps in params]
+        dev = self.device
+        self.x, self.mask, self.y, self.gy, self.gx, self.gmask, self.ctx, self.scratch = ([] for _ in range(8))
+        n_grad = sum(p.numel() for ps in self.params for p in ps)
+        self.grad_bucket = torch.zeros(n_grad, dtype=torch.float32, device=dev)
+        self.param_grads: List[List[torch.Tensor]] = []
+        self._fwd = (_lib.FwdLevel * self.n)()
+        self._bwd = (_lib.BwdLevel * self.n)()
+        off = 0
+        for l, ((B, C, H, W), ps, cfg) in enumerate(zip(shapes, self.params, cfgs)):
+            mk = lambda *s, dt=dtype: torch.zeros(*s, dtype=dt, device=dev)
+            self.x.append(mk(B, C, H, W)); self.y.append(mk(B, C, H, W)); self.gy.append(mk(B, C, H, W)); self.gx.append(mk(B, C, H, W))
+            self.mask.append(mk(B, 1, H, W, dt=torch.float32) if with_mask else None)
+            self.gmask.append(mk(B, 1, H, W, dt=torch.float32) if (with_mask and want_gmask) else None)
+            self.ctx.append(torch.zeros(_lib.ctx_bytes(B, C, H, W, cfg.hidden), dtype=torch.uint8, device=dev))
+            self.scratch.append(torch.zeros(_lib.scratch_bytes(B, C, H, W, cfg.hidden, cfg.k), dtype=torch.uint8, device=dev))
+            views = []
+            for p in ps:
+                views.append(self.grad_bucket[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+            self.param_grads.append(views)
+            ptr = lambda t: None if t is None else t.data_ptr()
+            F, Bw = self._fwd[l], self._bwd[l]
+            F.x, F.mask, F.y, F.ctx = ptr(self.x[l]), ptr(self.mask[l]), ptr(self.y[l]), ptr(self.ctx[l])
+            F.p = _params_struct(ps, cfg)
+            F.B, F.C, F.H, F.W, F.dtype = B, C, H, W, _DTYPES[dtype]
+            Bw.x, Bw.mask, Bw.gy, Bw.ctx, Bw.scratch = ptr(self.x[l]), ptr(self.mask[l]), ptr(self.gy[l]), ptr(self.ctx[l]), ptr(self.scratch[l])
+            Bw.gx, Bw.gmask = ptr(self.gx[l]), ptr(self.gmask[l])
+            Bw.gw1, Bw.gb1, Bw.gw2, Bw.gb2, Bw.gwsa, Bw.gbeta = (v.data_ptr() for v in views)
+            Bw.p = _params_struct(ps, cfg)
+            Bw.B, Bw.C, Bw.H, Bw.W, Bw.dtype = B, C, H, W, _DTYPES[dtype]
+
+    # ------------------------------------------------------------------ library calls on the current stream
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def forward(self, stages: int = _lib.FWD_ALL):
+        _lib.check(self.lib.mgacbam_forward_stages(self._fwd, self.n, stages, self._stream()), "mgacbam_forward_stages")
+
+    def backward(self, stages: int = _lib.BWD_ALL):
+        _lib.check(self.lib.mgacbam_backward_stages(self._bwd, self.n, stages, self._stream()), "mgacbam_backward_stages")
+
+    def backward_params(self):
+        self.backward(_lib.BWD_PARAMS)
+
+    def backward_inputs(self):
+        self.backward(_lib.BWD_INPUTS)
+
+    # ------------------------------------------------------------------ hipGraph capture
+    def capture(self, fn) -> "torch.cuda.CUDAGraph":
+        """Record ``fn()`` (library calls on this plan) into a graph; warm up on a side stream first, as capture requires."""
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g
+
+    # ------------------------------------------------------------------ sizes / inspection
+    def elements(self) -> int:
+        """E = sum over levels of B*C*H*W."""
+        return sum(B * C * H * W for B, C, H, W in self.shapes)
+
+    def images(self) -> int:
+        return self.shapes[0][0]
+
+    def ctx_view(self, level: int) -> dict:
+        B, C, H, W = self.shapes[level]
+        return ctx_views(self.ctx[level], B, C, H, W, self.cfgs[level].hidden)
+
+    def named_param_grads(self, level: int) -> dict:
+        return dict(zip(("g" + n for n in PARAM_NAMES), self.param_grads[level]))
