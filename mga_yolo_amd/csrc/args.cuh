@@ -59,9 +59,21 @@ struct BwdArgs {
   float* gw1; float* gb1; float* gw2; float* gb2; float* gwsa; float* gbeta;
   CtxPtrs c; ParamPtrs p; ScratchPtrs s; Geo g; Tune t;
   int nt;       // hw tiles of k_bwd_reduce1
-  int nconv;    // workgroups of k_bwd_convT
+  int nconv;    // conv tiles of this level (B * tiles_y * tiles_x): one dWsa partial each
+  int r2_blocks;// workgroups of the streaming part of k_bwd_reduce2 (the dWsa role blocks follow them)
 };
 
 static inline size_t align16(size_t v) { return (v + 15) & ~size_t(15); }
+
+// One launch covers up to kGroupMax pyramid levels: workgroup ids [start[l], start[l+1]) belong to level l.
+// P3+P4+P5 of YOLOv8n are 52+26+13 MB -- alone, P5 cannot fill 256 CUs and every extra launch costs ~2.7 us of
+// dependent-kernel boundary, so each stage is ONE launch whose grid is the concatenation of the levels' grids.
+constexpr int kGroupMax = 4;
+template <typename Args>
+struct Group {
+  int n;
+  int start[kGroupMax + 1];
+  Args lv[kGroupMax];
+};
 
 }  // namespace mgacbam

@@ -17,6 +17,7 @@
 #pragma once
 #include "args.cuh"
 #include "common.cuh"
+#include "fwd.cuh"   // ConvTile / stage_tiles
 
 namespace mgacbam {
 
@@ -87,114 +88,123 @@ __device__ __forceinline__ void bwd_reduce1_body(const BwdArgs& A, const int bid
 }
 
 template <typename T, int VEC>
-__global__ __launch_bounds__(kBlock) void k_bwd_reduce1(const BwdArgs A) {
+__global__ __launch_bounds__(kBlock) void k_bwd_reduce1(const Group<BwdArgs> G) {
   __shared__ float sm[kBlock * VEC];
-  bwd_reduce1_body<T, VEC>(A, blockIdx.x, sm);
+  int local;
+  const int l = find_level(G, blockIdx.x, local);
+  bwd_reduce1_body<T, VEC>(G.lv[l], local, sm);
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_bwd_convT: g_planes[p] = sum_{i,j} W[p,i,j] * g_pre[h-i+pad, w-j+pad]   (transposed conv)
-//              dW partial  = sum_{px in tile} g_pre[px] * planes[p][px + (i,j) - pad]
-//   same tiling as k_conv_fwd; LDS holds the g_pre tile + halo and the 3 plane tiles + halo.
+// k_bwd_convT: g_planes[p] = sum_{i,j} W[p,i,j] * g_pre[h-i+pad, w-j+pad]   (transposed conv, flipped kernel)
+//   same tiling as k_conv_fwd; LDS holds the g_pre tile + halo; 4 adjacent pixels x 3 planes per thread.
 // ---------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(kBlock) void k_bwd_convT(const BwdArgs A) {
-  extern __shared__ float tile[];
+__global__ __launch_bounds__(kBlock) void k_bwd_convT(const Group<BwdArgs> G) {
+  extern __shared__ float smem[];
+  int local;
+  const int lvl = find_level(G, blockIdx.x, local);
+  const BwdArgs& A = G.lv[lvl];
   const Geo& g = A.g;
-  const int k = K ? K : g.k, pad = k / 2;
-  const int TWQ = A.t.conv_twq, TH = A.t.conv_th, TW = TWQ * 4;
-  const int PW = TW + k - 1, PH = TH + k - 1;
-  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
-  int bid = blockIdx.x;
-  const int txi = bid % tiles_x; bid /= tiles_x;
-  const int tyi = bid % tiles_y;
-  const int b = bid / tiles_y;
-  const int y0 = tyi * TH, x0 = txi * TW;
+  const int k = K ? K : g.k;
+  const ConvTile c = conv_tile(g, A.t, k, local);
   const int tid = threadIdx.x;
-  const int plane_elems = PH * PW;
-  float* tg = tile;                      // g_pre   tile + halo
-  float* tp = tile + plane_elems;        // planes  tile + halo (3 planes)
-  const float* gpre = A.s.gpre + static_cast<size_t>(b) * g.HW;
-  const float* pl = A.c.planes + static_cast<size_t>(b) * 3 * g.HW;
-
-  for (int idx = tid; idx < 4 * plane_elems; idx += kBlock) {
-    const int p = idx / plane_elems, r = idx - p * plane_elems;
-    const int yy = r / PW, xx = r - yy * PW;
-    const int gy_ = y0 + yy - pad, gx_ = x0 + xx - pad;
-    float v = 0.f;
-    if (gy_ >= 0 && gy_ < g.H && gx_ >= 0 && gx_ < g.W)
-      v = (p == 0) ? gpre[gy_ * g.W + gx_] : pl[static_cast<size_t>(p - 1) * g.HW + gy_ * g.W + gx_];
-    tile[idx] = v;
-  }
+  float* wts = smem;
+  float* tg = smem + ((3 * k * k + 3) & ~3);
+  for (int i = tid; i < 3 * k * k; i += kBlock) wts[i] = A.p.wsa[i];
+  const float* gpre = A.s.gpre + static_cast<size_t>(c.b) * g.HW;
+  stage_tiles<1>(tg, c, g, [&](int) { return gpre; });
   __syncthreads();
-
-  // ---- g_planes for the tile interior: 4 adjacent pixels x 3 planes per thread -----------------
-  const float* w = A.p.wsa;
+  const int TWQ = A.t.conv_twq;
   const int py = tid / TWQ, q = tid - py * TWQ;
-  if (py < TH) {
-    float acc[3][4];
+  if (py >= c.TH) return;
+  float acc[3][4];
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+  for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[p][e] = 0.f;
-    if (K) {
+    for (int e = 0; e < 4; ++e) acc[p][e] = 0.f;
+  constexpr int KK = K ? K : 1;
+  if (K) {
+#pragma unroll 1
+    for (int i = 0; i < KK; ++i) {
+      const float* row = tg + (py + i) * c.PW + q * 4;
+      float r[4 + KK - 1];
 #pragma unroll
-      for (int i = 0; i < (K ? K : 1); ++i) {
-        const float* row = tg + (py + i) * PW + q * 4;
-        float r[4 + (K ? K : 1) - 1];
+      for (int t = 0; t < 4 + KK - 1; ++t) r[t] = row[t];
 #pragma unroll
-        for (int t = 0; t < 4 + (K ? K : 1) - 1; ++t) r[t] = row[t];
+      for (int p = 0; p < 3; ++p) {
+        const float* wr = wts + (p * KK + (KK - 1 - i)) * KK;               // flipped kernel row
 #pragma unroll
-        for (int j = 0; j < (K ? K : 1); ++j) {
+        for (int j = 0; j < KK; ++j) {
+          const float wv = wr[KK - 1 - j];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
-            const float wv = w[(p * K + (K - 1 - i)) * K + (K - 1 - j)];     // flipped kernel
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[p][e] += wv * r[e + j];
-          }
-        }
-      }
-    } else {
-      for (int i = 0; i < k; ++i) {
-        const float* row = tg + (py + i) * PW + q * 4;
-        for (int j = 0; j < k; ++j) {
-#pragma unroll
-          for (int p = 0; p < 3; ++p) {
-            const float wv = w[(p * k + (k - 1 - i)) * k + (k - 1 - j)];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[p][e] += wv * row[e + j];
-          }
+          for (int e = 0; e < 4; ++e) acc[p][e] += wv * r[e + j];
         }
       }
     }
-    const int yg = y0 + py;
-    if (yg < g.H) {
+  } else {
+    for (int i = 0; i < k; ++i) {
+      const float* row = tg + (py + i) * c.PW + q * 4;
+      for (int j = 0; j < k; ++j) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int xg = x0 + q * 4 + e;
-        if (xg < g.W) {
+        for (int p = 0; p < 3; ++p) {
+          const float wv = wts[(p * k + (k - 1 - i)) * k + (k - 1 - j)];
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
-            A.s.gplanes[(static_cast<size_t>(b) * 3 + p) * g.HW + yg * g.W + xg] = acc[p][e];
+          for (int e = 0; e < 4; ++e) acc[p][e] += wv * row[e + j];
         }
       }
     }
   }
+  const int yg = c.y0 + py;
+  if (yg < g.H) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int xg = c.x0 + q * 4 + e;
+      if (xg < g.W) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          A.s.gplanes[(static_cast<size_t>(c.b) * 3 + p) * g.HW + yg * g.W + xg] = acc[p][e];
+      }
+    }
+  }
+}
 
-  // ---- dWsa partial of this tile: thread t < 3*k*k owns output (p,i,j) and walks the tile's pixels ----
+// ---------------------------------------------------------------------------------------------
+// dWsa partial of one conv tile:  sum_{px in tile} g_pre[px] * planes[p][px + (i,j) - pad]
+//   thread t < 3*k*k owns output (p,i,j) and walks the tile's pixels (LDS only).  This is LDS/VALU work with no
+//   HBM traffic, so these workgroups ride in front of the HBM-bound k_bwd_reduce2 grid ("role" blocks) and
+//   overlap with it instead of costing a launch of their own.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bwd_wsa_body(const BwdArgs& A, const int bid, float* tile) {
+  const Geo& g = A.g;
+  const int k = g.k;
+  const ConvTile c = conv_tile(g, A.t, k, bid);
+  const int plane_elems = c.PH * c.PW;
+  float* tg = tile;                      // g_pre tile + halo
+  float* tp = tile + plane_elems;        // 3 plane tiles + halo
+  const float* gpre = A.s.gpre + static_cast<size_t>(c.b) * g.HW;
+  const float* pl = A.c.planes + static_cast<size_t>(c.b) * 3 * g.HW;
+  stage_tiles<4>(tile, c, g, [&](int p) { return p == 0 ? gpre : pl + static_cast<size_t>(p - 1) * g.HW; });
+  __syncthreads();
   const int nout = 3 * k * k;
-  for (int o = tid; o < nout; o += kBlock) {
+  for (int o = threadIdx.x; o < nout; o += kBlock) {
     const int p = o / (k * k), r = o - p * k * k;
     const int i = r / k, j = r - i * k;
-    const float* pp = tp + p * plane_elems + i * PW + j;      // planes[p][y + i - pad][x + j - pad]
-    const float* gg = tg + pad * PW + pad;                    // g_pre[y][x]
-    float acc = 0.f;
-    for (int yy = 0; yy < TH; ++yy) {
-      const float* prow = pp + yy * PW;
-      const float* grow = gg + yy * PW;
-      for (int xx = 0; xx < TW; ++xx) acc += grow[xx] * prow[xx];   // zero fill outside the image
+    const float* pp = tp + p * plane_elems + i * c.PW + j;      // planes[p][y + i - pad][x + j - pad]
+    const float* gg = tg + c.pad * c.PW + c.pad;                // g_pre[y][x]
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int yy = 0; yy < c.TH; ++yy) {
+      const float* prow = pp + yy * c.PW;
+      const float* grow = gg + yy * c.PW;
+#pragma unroll 4
+      for (int xx = 0; xx < c.TW; xx += 4) {                    // TW is a multiple of 4; zero fill outside the image
+        a0 += grow[xx] * prow[xx];
+        a1 += grow[xx + 1] * prow[xx + 1];
+        a2 += grow[xx + 2] * prow[xx + 2];
+        a3 += grow[xx + 3] * prow[xx + 3];
+      }
     }
-    A.s.gwsa_part[static_cast<size_t>(blockIdx.x) * nout + o] = acc;
+    A.s.gwsa_part[static_cast<size_t>(o) * A.nconv + bid] = (a0 + a1) + (a2 + a3);
   }
 }
 
@@ -265,20 +275,28 @@ __device__ __forceinline__ void bwd_reduce2_body(const BwdArgs& A, const int bid
   }
 }
 
+// grid of a level = [nconv dWsa role workgroups][streaming workgroups]
 template <typename T, int VEC, int CPT>
-__global__ __launch_bounds__(kBlock) void k_bwd_reduce2(const BwdArgs A) {
-  __shared__ float red[64];
-  bwd_reduce2_body<T, VEC, CPT>(A, blockIdx.x, red);
+__global__ __launch_bounds__(kBlock) void k_bwd_reduce2(const Group<BwdArgs> G) {
+  extern __shared__ float smem[];       // role blocks: 4 conv tiles; streaming blocks: 64 floats of reduction scratch
+  int local;
+  const int l = find_level(G, blockIdx.x, local);
+  const BwdArgs& A = G.lv[l];
+  if (local < A.nconv) bwd_wsa_body(A, local, smem);
+  else bwd_reduce2_body<T, VEC, CPT>(A, local - A.nconv, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_bwd_mlp: backward of the shared MLP for both applications (inputs avg and mx); one workgroup per sample
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_bwd_mlp(const BwdArgs A) {
+__global__ __launch_bounds__(kBlock) void k_bwd_mlp(const Group<BwdArgs> G) {
   extern __shared__ float sm[];
   __shared__ float red[8];
+  int local;
+  const int lvl = find_level(G, blockIdx.x, local);
+  const BwdArgs& A = G.lv[lvl];
   const Geo& g = A.g;
-  const int b = blockIdx.x, tid = threadIdx.x, C = g.C, h = g.hidden;
+  const int b = local, tid = threadIdx.x, C = g.C, h = g.hidden;
   float* s_gz = sm;           // C
   float* s_ga = sm + C;       // h  gh_avg
   float* s_gm = s_ga + h;     // h  gh_mx
@@ -408,34 +426,54 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
 }
 
 template <typename T, int VEC, bool GMASK>
-__global__ __launch_bounds__(kBlock) void k_bwd_apply(const BwdArgs A) {
+__global__ __launch_bounds__(kBlock) void k_bwd_apply(const Group<BwdArgs> G) {
   __shared__ float sm[kBlock * VEC];
-  bwd_apply_body<T, VEC, GMASK>(A, blockIdx.x, sm);
+  int local;
+  const int l = find_level(G, blockIdx.x, local);
+  bwd_apply_body<T, VEC, GMASK>(G.lv[l], local, sm);
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_bwd_finalize: parameter gradients from per-sample / per-workgroup partials (one reader per output)
-//   outputs, in order: dW1 (h*C), db1 (h), dW2 (C*h), db2 (C), dWsa (3*k*k); last workgroup: dbeta
+// k_bwd_finalize: parameter gradients from per-sample / per-tile partials (one reader per output, fixed order)
+//   workgroup roles inside a level: [0, nb_mlp) thread-per-output over dW1 (h*C), db1 (h), dW2 (C*h), db2 (C),
+//   each a sum over the B samples; [nb_mlp, nb_mlp + nb_wsa) wave-per-output over the nconv dWsa partials;
+//   last workgroup: dbeta = sigmoid(beta) * sum_{b,c} (ca*A - Q).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_bwd_finalize(const BwdArgs A) {
+__global__ __launch_bounds__(kBlock) void k_bwd_finalize(const Group<BwdArgs> G) {
   __shared__ float red[8];
+  int local;
+  const int lvl = find_level(G, blockIdx.x, local);
+  const BwdArgs& A = G.lv[lvl];
   const Geo& g = A.g;
   const int C = g.C, h = g.hidden, B = g.B, kk3 = 3 * g.k * g.k;
   const int n_w1 = h * C, n_b1 = h, n_w2 = C * h, n_b2 = C;
-  const int total = n_w1 + n_b1 + n_w2 + n_b2 + kk3;
+  const int total = n_w1 + n_b1 + n_w2 + n_b2;
+  const int nb_mlp = (total + kBlock - 1) / kBlock;
+  const int nb_wsa = (kk3 + 3) / 4;
   const int tid = threadIdx.x;
-  if (blockIdx.x == gridDim.x - 1) {                            // dbeta = sigmoid(beta) * sum_{b,c} (ca*A - Q)
+  if (local >= nb_mlp + nb_wsa) {                              // dbeta
     float acc = 0.f;
     for (int o = tid; o < B * C; o += kBlock) acc += A.s.gbq[o];
     acc = block_sum(acc, tid, red);
     if (tid == 0) *A.gbeta = sigmoidf_(*A.p.beta) * acc;
     return;
   }
-  int o = blockIdx.x * kBlock + tid;
+  if (local >= nb_mlp) {                                       // dWsa[p,i,j] = sum over conv tiles (lanes stride the partials)
+    const int o = (local - nb_mlp) * 4 + (tid >> 6), lane = tid & 63;
+    if (o >= kk3) return;
+    const float* part = A.s.gwsa_part + static_cast<size_t>(o) * A.nconv;
+    float acc = 0.f;
+    for (int t = lane; t < A.nconv; t += kWave) acc += part[t];
+    acc = wave_group_sum(acc, kWave);
+    if (lane == 0) A.gwsa[o] = acc;
+    return;
+  }
+  int o = local * kBlock + tid;
   if (o >= total) return;
   if (o < n_w1) {                                              // dW1[j,c] = sum_b gh_avg[b,j]*avg[b,c] + gh_mx[b,j]*mx[b,c]
     const int j = o / C, c = o - j * C;
     float acc = 0.f;
+#pragma unroll 8
     for (int b = 0; b < B; ++b)
       acc += A.s.gh_avg[b * h + j] * A.c.avg[static_cast<size_t>(b) * C + c] + A.s.gh_mx[b * h + j] * A.c.mx[static_cast<size_t>(b) * C + c];
     A.gw1[o] = acc;
@@ -444,6 +482,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_finalize(const BwdArgs A) {
   o -= n_w1;
   if (o < n_b1) {                                              // db1[j] = sum_b gh_avg + gh_mx
     float acc = 0.f;
+#pragma unroll 8
     for (int b = 0; b < B; ++b) acc += A.s.gh_avg[b * h + o] + A.s.gh_mx[b * h + o];
     A.gb1[o] = acc;
     return;
@@ -452,22 +491,17 @@ __global__ __launch_bounds__(kBlock) void k_bwd_finalize(const BwdArgs A) {
   if (o < n_w2) {                                              // dW2[c,j] = sum_b g_z[b,c] * (h_avg[b,j] + h_mx[b,j])
     const int c = o / h, j = o - c * h;
     float acc = 0.f;
+#pragma unroll 8
     for (int b = 0; b < B; ++b) acc += A.s.gz[static_cast<size_t>(b) * C + c] * (A.c.h_avg[b * h + j] + A.c.h_mx[b * h + j]);
     A.gw2[o] = acc;
     return;
   }
   o -= n_w2;
-  if (o < n_b2) {                                              // db2[c] = 2 * sum_b g_z[b,c]   (bias used twice)
+  {                                                            // db2[c] = 2 * sum_b g_z[b,c]   (bias used twice)
     float acc = 0.f;
+#pragma unroll 8
     for (int b = 0; b < B; ++b) acc += A.s.gz[static_cast<size_t>(b) * C + o];
     A.gb2[o] = 2.f * acc;
-    return;
-  }
-  o -= n_b2;
-  {                                                            // dWsa[p,i,j] = sum over conv workgroups
-    float acc = 0.f;
-    for (int t = 0; t < A.nconv; ++t) acc += A.s.gwsa_part[static_cast<size_t>(t) * kk3 + o];
-    A.gwsa[o] = acc;
   }
 }
 

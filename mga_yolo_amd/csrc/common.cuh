@@ -6,6 +6,8 @@
 #include <float.h>
 #include <stdint.h>
 
+#include "args.cuh"
+
 namespace mgacbam {
 
 constexpr int kBlock = 256;        // every kernel uses 256-thread workgroups = 4 waves
@@ -59,6 +61,11 @@ __device__ __forceinline__ void store_ivec(int* __restrict__ p, const int (&in)[
 // scalar math
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// per-pixel sigmoid on the streaming path: v_exp_f32 + v_rcp_f32 (relative error ~1e-6, two transcendental issues);
+// the accurate expf costs ~10x the VALU slots and made k_pool VALU-bound instead of HBM-bound
+__device__ __forceinline__ float sigmoid_fast(float v) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
 // torch.nn.functional.softplus(beta=1, threshold=20)  (masked_cbam.py:150-152)
 __device__ __forceinline__ float softplusf_(float v) { return v > 20.0f ? v : log1pf(expf(v)); }
 // torch.isclose(a, b) with the default rtol=1e-5, atol=1e-8 (masked_cbam.py:120)
@@ -145,5 +152,16 @@ __device__ __forceinline__ float block_sum(float v, int tid, float* red) {
 }
 
 __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
+
+// level of a grouped launch that owns workgroup `bid`; returns the id relative to that level in `local`
+template <typename G>
+__device__ __forceinline__ int find_level(const G& g, int bid, int& local) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < kGroupMax; ++i)
+    if (i < g.n && bid >= g.start[i]) l = i;
+  local = bid - g.start[l];
+  return l;
+}
 
 }  // namespace mgacbam

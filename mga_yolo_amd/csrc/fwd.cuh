@@ -58,7 +58,7 @@ __device__ __forceinline__ void pool_body(const FwdArgs& A, const int bid, float
       load_vec<float, VEC>(mb + static_cast<size_t>(i) * VEC, m);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        s[e] = g.use_sigmoid ? sigmoidf_(m[e]) : m[e];     // masked_cbam.py:93-94
+        s[e] = g.use_sigmoid ? sigmoid_fast(m[e]) : m[e];   // masked_cbam.py:93-94
         sel[e] = s[e] > 0.5f;                               // masked_cbam.py:116
         ssum += s[e];
       }
@@ -123,19 +123,24 @@ __device__ __forceinline__ void pool_body(const FwdArgs& A, const int bid, float
 }
 
 template <typename T, int VEC, int CPT, bool HAS_MASK>
-__global__ __launch_bounds__(kBlock) void k_pool(const FwdArgs A) {
+__global__ __launch_bounds__(kBlock) void k_pool(const Group<FwdArgs> G) {
   __shared__ float red[64];
-  pool_body<T, VEC, CPT, HAS_MASK>(A, blockIdx.x, red);
+  int local;
+  const int l = find_level(G, blockIdx.x, local);
+  pool_body<T, VEC, CPT, HAS_MASK>(G.lv[l], local, red);
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_mlp_fwd: shared MLP on both descriptors, channel gate                     masked_cbam.py:54-58, 128-129
 //   one workgroup per sample; <= 74k MAC per sample -- far too small for MFMA
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_mlp_fwd(const FwdArgs A) {
+__global__ __launch_bounds__(kBlock) void k_mlp_fwd(const Group<FwdArgs> G) {
   extern __shared__ float sm[];
+  int local;
+  const int lvl = find_level(G, blockIdx.x, local);
+  const FwdArgs& A = G.lv[lvl];
   const Geo& g = A.g;
-  const int b = blockIdx.x, tid = threadIdx.x, C = g.C, h = g.hidden;
+  const int b = local, tid = threadIdx.x, C = g.C, h = g.hidden;
   float* s_avg = sm;
   float* s_mx = sm + C;
   float* s_ha = sm + 2 * C;
@@ -235,59 +240,100 @@ __device__ __forceinline__ void chan_body(const FwdArgs& A, const int bid, float
 }
 
 template <typename T, int VEC>
-__global__ __launch_bounds__(kBlock) void k_chan(const FwdArgs A) {
+__global__ __launch_bounds__(kBlock) void k_chan(const Group<FwdArgs> G) {
   __shared__ float sm[kBlock * VEC * 3];
-  chan_body<T, VEC>(A, blockIdx.x, sm);
+  int local;
+  const int l = find_level(G, blockIdx.x, local);
+  chan_body<T, VEC>(G.lv[l], local, sm);
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv tiles (shared by k_conv_fwd and the backward conv kernels)
+//   a tile is TH rows x TW = 4*TWQ columns of one sample; NP planes of (TH+k-1) x (TW+k-1) floats (tile + halo,
+//   zero padded outside the image) are staged in LDS.  Loads are issued 8 at a time per thread before any LDS
+//   store so the global-load latency is paid once per batch, not once per element.
+// ---------------------------------------------------------------------------------------------
+struct ConvTile {
+  int b, y0, x0, TW, TH, PW, PH, pad, k;
+};
+__device__ __forceinline__ ConvTile conv_tile(const Geo& g, const Tune& t, int k, int bid) {
+  ConvTile c;
+  c.k = k; c.pad = k / 2;
+  c.TW = t.conv_twq * 4; c.TH = t.conv_th;
+  c.PW = c.TW + k - 1; c.PH = c.TH + k - 1;
+  const int tiles_x = (g.W + c.TW - 1) / c.TW, tiles_y = (g.H + c.TH - 1) / c.TH;
+  const int txi = bid % tiles_x; bid /= tiles_x;
+  const int tyi = bid % tiles_y;
+  c.b = bid / tiles_y;
+  c.y0 = tyi * c.TH; c.x0 = txi * c.TW;
+  return c;
+}
+// src(p) -> pointer to plane p of this sample (H*W floats)
+template <int NP, typename SrcFn>
+__device__ __forceinline__ void stage_tiles(float* tile, const ConvTile& c, const Geo& g, SrcFn src) {
+  const int total = NP * c.PH * c.PW;
+  const unsigned mpw = 0xFFFFFFFFu / static_cast<unsigned>(c.PW) + 1u;    // idx / PW == umulhi(idx, mpw) for idx < 2^16
+  const unsigned mph = 0xFFFFFFFFu / static_cast<unsigned>(c.PH) + 1u;
+  for (int base = 0; base < total; base += kBlock * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * kBlock + threadIdx.x;
+      const unsigned r = __umulhi(static_cast<unsigned>(idx), mpw);        // row over all planes
+      const int xx = idx - static_cast<int>(r) * c.PW;
+      const unsigned p = __umulhi(r, mph);
+      const int yy = static_cast<int>(r) - static_cast<int>(p) * c.PH;
+      const int gy_ = c.y0 + yy - c.pad, gx_ = c.x0 + xx - c.pad;
+      v[u] = 0.f;
+      if (idx < total && gy_ >= 0 && gy_ < g.H && gx_ >= 0 && gx_ < g.W) v[u] = src(static_cast<int>(p))[gy_ * g.W + gx_];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * kBlock + threadIdx.x;
+      if (idx < total) tile[idx] = v[u];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_conv_fwd: sa = sigmoid(conv_kxk([max_c u, mean_c u, sigma(mask)]))         masked_cbam.py:146-147
-//   tile of TH rows x 4*TWQ columns per workgroup, 3 planes + halo staged in LDS (zero padded);
-//   each thread produces 4 adjacent pixels so one LDS row segment feeds k taps x 4 outputs.
-//   K > 0: compile-time kernel size (fully unrolled, weights come in through scalar loads); K == 0: any odd k.
+//   each thread produces 4 adjacent pixels so one LDS row segment of 4+k-1 floats feeds k taps x 4 outputs;
+//   weights sit in LDS (broadcast reads).  K > 0: compile-time kernel size; K == 0: any odd k <= 15.
 // ---------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(kBlock) void k_conv_fwd(const FwdArgs A) {
-  extern __shared__ float tile[];
+__global__ __launch_bounds__(kBlock) void k_conv_fwd(const Group<FwdArgs> G) {
+  extern __shared__ float smem[];
+  int local;
+  const int lvl = find_level(G, blockIdx.x, local);
+  const FwdArgs& A = G.lv[lvl];
   const Geo& g = A.g;
-  const int k = K ? K : g.k, pad = k / 2;
-  const int TWQ = A.t.conv_twq, TH = A.t.conv_th, TW = TWQ * 4;
-  const int PW = TW + k - 1, PH = TH + k - 1;
-  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
-  int bid = blockIdx.x;
-  const int txi = bid % tiles_x; bid /= tiles_x;
-  const int tyi = bid % tiles_y;
-  const int b = bid / tiles_y;
-  const int y0 = tyi * TH, x0 = txi * TW;
+  const int k = K ? K : g.k;
+  const ConvTile c = conv_tile(g, A.t, k, local);
   const int tid = threadIdx.x;
-  const float* pl = A.c.planes + static_cast<size_t>(b) * 3 * g.HW;
-
-  const int plane_elems = PH * PW;
-  for (int idx = tid; idx < 3 * plane_elems; idx += kBlock) {
-    const int p = idx / plane_elems, r = idx - p * plane_elems;
-    const int yy = r / PW, xx = r - yy * PW;
-    const int gy_ = y0 + yy - pad, gx_ = x0 + xx - pad;
-    float v = 0.f;
-    if (gy_ >= 0 && gy_ < g.H && gx_ >= 0 && gx_ < g.W) v = pl[static_cast<size_t>(p) * g.HW + gy_ * g.W + gx_];
-    tile[idx] = v;
-  }
+  float* wts = smem;                                   // 3*k*k (rounded up to a multiple of 4 floats)
+  float* tile = smem + ((3 * k * k + 3) & ~3);
+  for (int i = tid; i < 3 * k * k; i += kBlock) wts[i] = A.p.wsa[i];
+  const float* pl = A.c.planes + static_cast<size_t>(c.b) * 3 * g.HW;
+  stage_tiles<3>(tile, c, g, [&](int p) { return pl + static_cast<size_t>(p) * g.HW; });
   __syncthreads();
+  const int TWQ = A.t.conv_twq;
   const int py = tid / TWQ, q = tid - py * TWQ;
-  if (py >= TH) return;
+  if (py >= c.TH) return;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const float* w = A.p.wsa;
+  constexpr int KK = K ? K : 1;
   if (K) {
-#pragma unroll
+#pragma unroll 1
     for (int p = 0; p < 3; ++p) {
 #pragma unroll
-      for (int i = 0; i < (K ? K : 1); ++i) {
-        const float* row = tile + (p * PH + py + i) * PW + q * 4;
-        float r[4 + (K ? K : 1) - 1];
+      for (int i = 0; i < KK; ++i) {
+        const float* row = tile + (p * c.PH + py + i) * c.PW + q * 4;
+        const float* wr = wts + (p * KK + i) * KK;
+        float r[4 + KK - 1];
 #pragma unroll
-        for (int t = 0; t < 4 + (K ? K : 1) - 1; ++t) r[t] = row[t];
+        for (int t = 0; t < 4 + KK - 1; ++t) r[t] = row[t];
 #pragma unroll
-        for (int j = 0; j < (K ? K : 1); ++j) {
-          const float wv = w[(p * K + i) * K + j];
+        for (int j = 0; j < KK; ++j) {
+          const float wv = wr[j];
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[e] += wv * r[e + j];
         }
@@ -296,20 +342,21 @@ __global__ __launch_bounds__(kBlock) void k_conv_fwd(const FwdArgs A) {
   } else {
     for (int p = 0; p < 3; ++p)
       for (int i = 0; i < k; ++i) {
-        const float* row = tile + (p * PH + py + i) * PW + q * 4;
+        const float* row = tile + (p * c.PH + py + i) * c.PW + q * 4;
+        const float* wr = wts + (p * k + i) * k;
         for (int j = 0; j < k; ++j) {
-          const float wv = w[(p * k + i) * k + j];
+          const float wv = wr[j];
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[e] += wv * row[e + j];
         }
       }
   }
-  const int yg = y0 + py;
+  const int yg = c.y0 + py;
   if (yg < g.H) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int xg = x0 + q * 4 + e;
-      if (xg < g.W) A.c.sa[static_cast<size_t>(b) * g.HW + yg * g.W + xg] = sigmoidf_(acc[e]);
+      const int xg = c.x0 + q * 4 + e;
+      if (xg < g.W) A.c.sa[static_cast<size_t>(c.b) * g.HW + yg * g.W + xg] = sigmoidf_(acc[e]);
     }
   }
 }
@@ -366,8 +413,10 @@ __device__ __forceinline__ void apply_body(const FwdArgs& A, const int bid) {
 }
 
 template <typename T, int VEC, int CPT>
-__global__ __launch_bounds__(kBlock) void k_apply(const FwdArgs A) {
-  apply_body<T, VEC, CPT>(A, blockIdx.x);
+__global__ __launch_bounds__(kBlock) void k_apply(const Group<FwdArgs> G) {
+  int local;
+  const int l = find_level(G, blockIdx.x, local);
+  apply_body<T, VEC, CPT>(G.lv[l], local);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -9,6 +9,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "args.cuh"
 #include "bwd.cuh"
 #include "common.cuh"
@@ -202,10 +204,43 @@ static int check_params(const mgacbam_params_t& p) {
   return 0;
 }
 
+// Levels that share every compile-time property of the kernels (element type, vector width, mask / no mask,
+// conv size, dL/dmask wanted) are launched together: one grid per stage, the levels' grids concatenated.
+struct Sig {
+  int dtype, vec, has_mask, k, gmask;
+  bool operator==(const Sig& o) const { return dtype == o.dtype && vec == o.vec && has_mask == o.has_mask && k == o.k && gmask == o.gmask; }
+};
+
+// channels per thread for the row-sweep kernels, uniform over a group: the largest of {4,2,1} that still gives the
+// chip >= 6 workgroups per CU
+template <typename Args>
+static int group_cpt(const Args* lv, int n, bool apply_kernel) {
+  const int forced = env_int(apply_kernel ? "MGACBAM_APPLY_CPT" : "MGACBAM_POOL_CPT", 0);
+  if (forced == 1 || forced == 2 || forced == 4) return forced;
+  for (int cpt = 4; cpt > 1; cpt /= 2) {
+    long long blocks = 0;
+    for (int l = 0; l < n; ++l) {
+      const int tx = apply_kernel ? lv[l].t.apply_tx : lv[l].t.pool_tx;
+      const int cpb = (kBlock / tx) * cpt;
+      blocks += static_cast<long long>(lv[l].g.B) * ((lv[l].g.C + cpb - 1) / cpb);
+    }
+    if (blocks >= 1536) return cpt;
+  }
+  return 1;
+}
+template <typename Args>
+static int sweep_blocks(const Args& a, int tx, int cpt) {
+  const int cpb = (kBlock / tx) * cpt;
+  return a.g.B * ((a.g.C + cpb - 1) / cpb);
+}
+static size_t conv_smem(const Tune& t, int k, int planes) {
+  return (((3 * k * k + 3) & ~3) + static_cast<size_t>(planes) * (t.conv_th + k - 1) * (t.conv_twq * 4 + k - 1)) * sizeof(float);
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-static int forward_level(const mgacbam_fwd_level_t& L, int stages, hipStream_t st) {
+static int forward_args(const mgacbam_fwd_level_t& L, FwdArgs& A, Sig& sig) {
   if (!L.x || !L.y || !L.ctx) return fail(MGACBAM_E_NULL, "forward: x / y / ctx is NULL");
   if (int e = check_params(L.p)) return e;
   if (int e = check_shape(L.B, L.C, L.H, L.W, L.p.hidden, L.p.k)) return e;
@@ -214,59 +249,80 @@ static int forward_level(const mgacbam_fwd_level_t& L, int stages, hipStream_t s
   const size_t need = VEC * elem_size(L.dtype);
   if (!aligned_to(L.x, need) || !aligned_to(L.y, need) || !aligned_to(L.ctx, 16) || (L.mask && !aligned_to(L.mask, VEC * 4)))
     return fail(MGACBAM_E_ALIGN, "forward: x/y must be %zu-byte aligned, ctx 16-byte, mask %d-byte", need, VEC * 4);
-
-  FwdArgs A;
   A.x = L.x; A.mask = L.mask; A.y = L.y;
   A.c = ctx_ptrs(L.ctx, L.B, L.C, L.H, L.W, L.p.hidden);
   A.p = make_params(L.p);
   A.g = make_geo(L.B, L.C, L.H, L.W, L.p);
   A.t = choose_tune(L.B, L.C, L.H, L.W);
-  const Geo& g = A.g;
-  const int nv = g.HW / VEC;
-  const bool has_mask = L.mask != nullptr;
+  sig = Sig{L.dtype, VEC, L.mask != nullptr, L.p.k, 0};
+  return 0;
+}
+
+static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStream_t st) {
+  Group<FwdArgs> G;
+  G.n = n;
+  const int pool_cpt = group_cpt(lv, n, false), apply_cpt = group_cpt(lv, n, true);
+  for (int l = 0; l < n; ++l) { lv[l].t.pool_cpt = pool_cpt; lv[l].t.apply_cpt = apply_cpt; G.lv[l] = lv[l]; }
+  auto fill = [&](auto blocks_of) { int tot = 0; for (int l = 0; l < n; ++l) { G.start[l] = tot; tot += blocks_of(lv[l]); } G.start[n] = tot; return tot; };
 
   if (stages & MGACBAM_FWD_POOL) {  // 1. pooling
-    const int TY = kBlock / A.t.pool_tx, CPB = TY * A.t.pool_cpt;
-    const int grid = g.B * ((g.C + CPB - 1) / CPB);
-#define CALL_POOL2(CPTV) if (has_mask) LAUNCH((k_pool<TT, VV, CPTV, true>), grid, 0, st, A); else LAUNCH((k_pool<TT, VV, CPTV, false>), grid, 0, st, A)
-#define CALL_POOL(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; DISPATCH_CPT(A.t.pool_cpt, CALL_POOL2); }
-    DISPATCH_T_VEC(L.dtype, VEC, CALL_POOL);
+    const int grid = fill([&](const FwdArgs& a) { return sweep_blocks(a, a.t.pool_tx, pool_cpt); });
+#define CALL_POOL2(CPTV) if (sig.has_mask) LAUNCH((k_pool<TT, VV, CPTV, true>), grid, 0, st, G); else LAUNCH((k_pool<TT, VV, CPTV, false>), grid, 0, st, G)
+#define CALL_POOL(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; DISPATCH_CPT(pool_cpt, CALL_POOL2); }
+    DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_POOL);
 #undef CALL_POOL
 #undef CALL_POOL2
     if (int e = launch_status("k_pool")) return e;
   }
   if (stages & MGACBAM_FWD_MLP) {  // 2. shared MLP + channel gate
-    const size_t smem = (2 * static_cast<size_t>(g.C) + 2 * g.hidden) * sizeof(float);
-    LAUNCH(k_mlp_fwd, g.B, smem, st, A);
+    size_t smem = 0;
+    for (int l = 0; l < n; ++l) smem = std::max(smem, (2 * static_cast<size_t>(lv[l].g.C) + 2 * lv[l].g.hidden) * sizeof(float));
+    const int grid = fill([&](const FwdArgs& a) { return a.g.B; });
+    LAUNCH(k_mlp_fwd, grid, smem, st, G);
     if (int e = launch_status("k_mlp_fwd")) return e;
   }
   if (stages & MGACBAM_FWD_CHAN) {  // 3. channel max / mean planes
-    const int grid = g.B * ((nv + A.t.chan_tx - 1) / A.t.chan_tx);
-#define CALL_CHAN(Tt, Vv) LAUNCH((k_chan<Tt, Vv>), grid, 0, st, A)
-    DISPATCH_T_VEC(L.dtype, VEC, CALL_CHAN);
+    const int grid = fill([&](const FwdArgs& a) { return a.g.B * chan_tiles(a.t, a.g.H, a.g.W); });
+#define CALL_CHAN(Tt, Vv) LAUNCH((k_chan<Tt, Vv>), grid, 0, st, G)
+    DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_CHAN);
 #undef CALL_CHAN
     if (int e = launch_status("k_chan")) return e;
   }
   if (stages & MGACBAM_FWD_CONV) {  // 4. k x k conv + sigmoid
-    const int grid = g.B * conv_tiles(A.t, g.H, g.W);
-    const size_t smem = 3 * static_cast<size_t>(A.t.conv_th + g.k - 1) * (A.t.conv_twq * 4 + g.k - 1) * sizeof(float);
-    switch (g.k) {
-      case 3: LAUNCH(k_conv_fwd<3>, grid, smem, st, A); break;
-      case 5: LAUNCH(k_conv_fwd<5>, grid, smem, st, A); break;
-      case 7: LAUNCH(k_conv_fwd<7>, grid, smem, st, A); break;
-      default: LAUNCH(k_conv_fwd<0>, grid, smem, st, A); break;
+    size_t smem = 0;
+    for (int l = 0; l < n; ++l) smem = std::max(smem, conv_smem(lv[l].t, sig.k, 3));
+    const int grid = fill([&](const FwdArgs& a) { return a.g.B * conv_tiles(a.t, a.g.H, a.g.W); });
+    switch (sig.k) {
+      case 3: LAUNCH(k_conv_fwd<3>, grid, smem, st, G); break;
+      case 5: LAUNCH(k_conv_fwd<5>, grid, smem, st, G); break;
+      case 7: LAUNCH(k_conv_fwd<7>, grid, smem, st, G); break;
+      default: LAUNCH(k_conv_fwd<0>, grid, smem, st, G); break;
     }
     if (int e = launch_status("k_conv_fwd")) return e;
   }
   if (stages & MGACBAM_FWD_APPLY) {  // 5. apply both gates + alpha residual
-    const int TY = kBlock / A.t.apply_tx, CPB = TY * A.t.apply_cpt;
-    const int grid = g.B * ((g.C + CPB - 1) / CPB);
-#define CALL_APPLY2(CPTV) LAUNCH((k_apply<TT, VV, CPTV>), grid, 0, st, A)
-#define CALL_APPLY(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; DISPATCH_CPT(A.t.apply_cpt, CALL_APPLY2); }
-    DISPATCH_T_VEC(L.dtype, VEC, CALL_APPLY);
+    const int grid = fill([&](const FwdArgs& a) { return sweep_blocks(a, a.t.apply_tx, apply_cpt); });
+#define CALL_APPLY2(CPTV) LAUNCH((k_apply<TT, VV, CPTV>), grid, 0, st, G)
+#define CALL_APPLY(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; DISPATCH_CPT(apply_cpt, CALL_APPLY2); }
+    DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_APPLY);
 #undef CALL_APPLY
 #undef CALL_APPLY2
     if (int e = launch_status("k_apply")) return e;
+  }
+  return 0;
+}
+
+// partition the levels into launch groups (same signature, at most kGroupMax levels) and run `run` on each
+template <typename Args, typename Run>
+static int for_each_group(Args* args, const Sig* sigs, int n, Run run) {
+  bool done[MGACBAM_MAX_LEVELS] = {false};
+  for (int l = 0; l < n; ++l) {
+    if (done[l]) continue;
+    Args grp[kGroupMax];
+    int m = 0;
+    for (int j = l; j < n && m < kGroupMax; ++j)
+      if (!done[j] && sigs[j] == sigs[l]) { grp[m++] = args[j]; done[j] = true; }
+    if (int e = run(grp, m, sigs[l])) return e;
   }
   return 0;
 }
@@ -275,8 +331,11 @@ extern "C" int mgacbam_forward_stages(const mgacbam_fwd_level_t* levels, int n_l
   if (!levels) return fail(MGACBAM_E_NULL, "levels is NULL");
   if (n_levels < 1 || n_levels > MGACBAM_MAX_LEVELS) return fail(MGACBAM_E_LEVELS, "n_levels=%d", n_levels);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  FwdArgs args[MGACBAM_MAX_LEVELS];
+  Sig sigs[MGACBAM_MAX_LEVELS];
   for (int l = 0; l < n_levels; ++l)
-    if (int e = forward_level(levels[l], stages, st)) return e;
+    if (int e = forward_args(levels[l], args[l], sigs[l])) return e;
+  if (int e = for_each_group(args, sigs, n_levels, [&](FwdArgs* g, int m, const Sig& s) { return forward_group(g, m, s, stages, st); })) return e;
   g_err[0] = 0;
   return 0;
 }
@@ -287,7 +346,7 @@ extern "C" int mgacbam_forward(const mgacbam_fwd_level_t* levels, int n_levels, 
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-static int backward_level(const mgacbam_bwd_level_t& L, int stages, hipStream_t st) {
+static int backward_args(const mgacbam_bwd_level_t& L, BwdArgs& A, Sig& sig) {
   if (!L.x || !L.gy || !L.ctx || !L.scratch || !L.gx) return fail(MGACBAM_E_NULL, "backward: x / gy / ctx / scratch / gx is NULL");
   if (!L.gw1 || !L.gb1 || !L.gw2 || !L.gb2 || !L.gwsa || !L.gbeta) return fail(MGACBAM_E_NULL, "backward: NULL parameter-gradient pointer");
   if (L.gmask && !L.mask) return fail(MGACBAM_E_NULL, "backward: gmask requested but mask is NULL");
@@ -299,15 +358,12 @@ static int backward_level(const mgacbam_bwd_level_t& L, int stages, hipStream_t 
   if (!aligned_to(L.x, need) || !aligned_to(L.gy, need) || !aligned_to(L.gx, need) || !aligned_to(L.ctx, 16) ||
       !aligned_to(L.scratch, 16) || (L.gmask && !aligned_to(L.gmask, VEC * 4)))
     return fail(MGACBAM_E_ALIGN, "backward: x/gy/gx must be %zu-byte aligned, ctx/scratch 16-byte", need);
-
-  BwdArgs A;
   A.x = L.x; A.mask = L.mask; A.gy = L.gy; A.gx = L.gx; A.gmask = L.gmask;
   A.gw1 = L.gw1; A.gb1 = L.gb1; A.gw2 = L.gw2; A.gb2 = L.gb2; A.gwsa = L.gwsa; A.gbeta = L.gbeta;
   A.c = ctx_ptrs(const_cast<void*>(L.ctx), L.B, L.C, L.H, L.W, L.p.hidden);
   A.p = make_params(L.p);
   A.g = make_geo(L.B, L.C, L.H, L.W, L.p);
   A.t = choose_tune(L.B, L.C, L.H, L.W);
-  const Geo& g = A.g;
   const ScratchLayout SL = scratch_layout(L.B, L.C, L.H, L.W, L.p.hidden, L.p.k);
   char* sp = static_cast<char*>(L.scratch);
   A.s.A_part = reinterpret_cast<float*>(sp + SL.A_part); A.s.Q_part = reinterpret_cast<float*>(sp + SL.Q_part);
@@ -316,52 +372,69 @@ static int backward_level(const mgacbam_bwd_level_t& L, int stages, hipStream_t 
   A.s.gz = reinterpret_cast<float*>(sp + SL.gz); A.s.gbq = reinterpret_cast<float*>(sp + SL.gbq);
   A.s.gh_avg = reinterpret_cast<float*>(sp + SL.gh_avg); A.s.gh_mx = reinterpret_cast<float*>(sp + SL.gh_mx);
   A.s.chan4 = reinterpret_cast<float*>(sp + SL.chan4); A.s.Kb = reinterpret_cast<float*>(sp + SL.Kb);
-  A.nt = chan_tiles(A.t, g.H, g.W);
-  A.nconv = g.B * conv_tiles(A.t, g.H, g.W);
-  const bool want_gmask = L.gmask != nullptr;
+  A.nt = chan_tiles(A.t, A.g.H, A.g.W);
+  A.nconv = A.g.B * conv_tiles(A.t, A.g.H, A.g.W);
+  A.r2_blocks = 0;
+  sig = Sig{L.dtype, VEC, L.mask != nullptr, L.p.k, L.gmask != nullptr};
+  return 0;
+}
+
+static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStream_t st) {
+  Group<BwdArgs> G;
+  G.n = n;
+  const int cpt = group_cpt(lv, n, false);
+  for (int l = 0; l < n; ++l) { lv[l].t.pool_cpt = cpt; lv[l].r2_blocks = sweep_blocks(lv[l], lv[l].t.pool_tx, cpt); G.lv[l] = lv[l]; }
+  auto fill = [&](auto blocks_of) { int tot = 0; for (int l = 0; l < n; ++l) { G.start[l] = tot; tot += blocks_of(lv[l]); } G.start[n] = tot; return tot; };
 
   if (stages & MGACBAM_BWD_REDUCE1) {  // 1. per-(b,c) and per-pixel reductions of gy*x
-    const int grid = g.B * A.nt;
-#define CALL_R1(Tt, Vv) LAUNCH((k_bwd_reduce1<Tt, Vv>), grid, 0, st, A)
-    DISPATCH_T_VEC(L.dtype, VEC, CALL_R1);
+    const int grid = fill([&](const BwdArgs& a) { return a.g.B * a.nt; });
+#define CALL_R1(Tt, Vv) LAUNCH((k_bwd_reduce1<Tt, Vv>), grid, 0, st, G)
+    DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_R1);
 #undef CALL_R1
     if (int e = launch_status("k_bwd_reduce1")) return e;
   }
-  if (stages & MGACBAM_BWD_CONVT) {  // 2. transposed conv + dWsa partials
-    const size_t smem = 4 * static_cast<size_t>(A.t.conv_th + g.k - 1) * (A.t.conv_twq * 4 + g.k - 1) * sizeof(float);
-    switch (g.k) {
-      case 3: LAUNCH(k_bwd_convT<3>, A.nconv, smem, st, A); break;
-      case 5: LAUNCH(k_bwd_convT<5>, A.nconv, smem, st, A); break;
-      case 7: LAUNCH(k_bwd_convT<7>, A.nconv, smem, st, A); break;
-      default: LAUNCH(k_bwd_convT<0>, A.nconv, smem, st, A); break;
+  if (stages & MGACBAM_BWD_CONVT) {  // 2. transposed conv
+    size_t smem = 0;
+    for (int l = 0; l < n; ++l) smem = std::max(smem, conv_smem(lv[l].t, sig.k, 1));
+    const int grid = fill([&](const BwdArgs& a) { return a.nconv; });
+    switch (sig.k) {
+      case 3: LAUNCH(k_bwd_convT<3>, grid, smem, st, G); break;
+      case 5: LAUNCH(k_bwd_convT<5>, grid, smem, st, G); break;
+      case 7: LAUNCH(k_bwd_convT<7>, grid, smem, st, G); break;
+      default: LAUNCH(k_bwd_convT<0>, grid, smem, st, G); break;
     }
     if (int e = launch_status("k_bwd_convT")) return e;
   }
-  if (stages & MGACBAM_BWD_REDUCE2) {  // 3. remaining part of g_ca (needs g_planes), g_z
-    const int TY = kBlock / A.t.pool_tx, CPB = TY * A.t.pool_cpt;
-    const int grid = g.B * ((g.C + CPB - 1) / CPB);
-#define CALL_R22(CPTV) LAUNCH((k_bwd_reduce2<TT, VV, CPTV>), grid, 0, st, A)
-#define CALL_R2(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; DISPATCH_CPT(A.t.pool_cpt, CALL_R22); }
-    DISPATCH_T_VEC(L.dtype, VEC, CALL_R2);
+  if (stages & MGACBAM_BWD_REDUCE2) {  // 3. rest of g_ca (needs g_planes), g_z; dWsa partials ride along as role workgroups
+    size_t smem = 64 * sizeof(float);
+    for (int l = 0; l < n; ++l) smem = std::max(smem, conv_smem(lv[l].t, sig.k, 4));
+    const int grid = fill([&](const BwdArgs& a) { return a.nconv + a.r2_blocks; });
+#define CALL_R22(CPTV) LAUNCH((k_bwd_reduce2<TT, VV, CPTV>), grid, smem, st, G)
+#define CALL_R2(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; DISPATCH_CPT(cpt, CALL_R22); }
+    DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_R2);
 #undef CALL_R2
 #undef CALL_R22
     if (int e = launch_status("k_bwd_reduce2")) return e;
   }
   if (stages & MGACBAM_BWD_MLP) {  // 4. shared-MLP backward
-    const size_t smem = (static_cast<size_t>(g.C) + 2 * g.hidden) * sizeof(float);
-    LAUNCH(k_bwd_mlp, g.B, smem, st, A);
+    size_t smem = 0;
+    for (int l = 0; l < n; ++l) smem = std::max(smem, (static_cast<size_t>(lv[l].g.C) + 2 * lv[l].g.hidden) * sizeof(float));
+    const int grid = fill([&](const BwdArgs& a) { return a.g.B; });
+    LAUNCH(k_bwd_mlp, grid, smem, st, G);
     if (int e = launch_status("k_bwd_mlp")) return e;
   }
   if (stages & MGACBAM_BWD_FINALIZE) {  // 5. parameter gradients (do not depend on stage 6)
-    const int total = 2 * g.C * g.hidden + g.C + g.hidden + 3 * g.k * g.k;
-    const int grid = (total + kBlock - 1) / kBlock + 1;
-    LAUNCH(k_bwd_finalize, grid, 0, st, A);
+    const int grid = fill([&](const BwdArgs& a) {
+      const int total = 2 * a.g.C * a.g.hidden + a.g.C + a.g.hidden;
+      return (total + kBlock - 1) / kBlock + (3 * a.g.k * a.g.k + 3) / 4 + 1;
+    });
+    LAUNCH(k_bwd_finalize, grid, 0, st, G);
     if (int e = launch_status("k_bwd_finalize")) return e;
   }
   if (stages & MGACBAM_BWD_APPLY) {  // 6. gx (+ gmask)
-    const int grid = g.B * A.nt;
-#define CALL_AP(Tt, Vv) if (want_gmask) LAUNCH((k_bwd_apply<Tt, Vv, true>), grid, 0, st, A); else LAUNCH((k_bwd_apply<Tt, Vv, false>), grid, 0, st, A)
-    DISPATCH_T_VEC(L.dtype, VEC, CALL_AP);
+    const int grid = fill([&](const BwdArgs& a) { return a.g.B * a.nt; });
+#define CALL_AP(Tt, Vv) if (sig.gmask) LAUNCH((k_bwd_apply<Tt, Vv, true>), grid, 0, st, G); else LAUNCH((k_bwd_apply<Tt, Vv, false>), grid, 0, st, G)
+    DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_AP);
 #undef CALL_AP
     if (int e = launch_status("k_bwd_apply")) return e;
   }
@@ -372,8 +445,11 @@ extern "C" int mgacbam_backward_stages(const mgacbam_bwd_level_t* levels, int n_
   if (!levels) return fail(MGACBAM_E_NULL, "levels is NULL");
   if (n_levels < 1 || n_levels > MGACBAM_MAX_LEVELS) return fail(MGACBAM_E_LEVELS, "n_levels=%d", n_levels);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  BwdArgs args[MGACBAM_MAX_LEVELS];
+  Sig sigs[MGACBAM_MAX_LEVELS];
   for (int l = 0; l < n_levels; ++l)
-    if (int e = backward_level(levels[l], stages, st)) return e;
+    if (int e = backward_args(levels[l], args[l], sigs[l])) return e;
+  if (int e = for_each_group(args, sigs, n_levels, [&](BwdArgs* g, int m, const Sig& s) { return backward_group(g, m, s, stages, st); })) return e;
   g_err[0] = 0;
   return 0;
 }
