@@ -6,7 +6,8 @@
 A *step* is one pass of the hot path over one batch: MaskCBAM forward + backward at P3, P4 and P5 (YOLOv8n channel
 widths, 640x640 input -> 80/40/20 px feature maps, batch 32 per GPU, fp32, random masks = BASELINE.json configs[1]),
 followed -- when N > 1 -- by the data-parallel exchange of the block's parameter gradients (one flat bucket, RCCL
-all-reduce, overlapped with the input-gradient kernel).  Inputs are synthetic and already resident in HBM when timing
+all-reduce on a side stream; it overlaps the NEXT step's parameter-free prefix (k_pool) and is joined before the first
+kernel that reads a parameter, which is the DDP contract: averaged gradients before the next use of the weights).  Inputs are synthetic and already resident in HBM when timing
 starts.  For N > 1 the driver starts one process per GPU with torch.distributed.run; RANK / LOCAL_RANK / WORLD_SIZE /
 MASTER_* are read from the environment.  Rank 0 prints ONE JSON line:
 
@@ -45,9 +46,8 @@ WORKLOADS = {
 # algorithmic bytes of each HBM-bound kernel in units of E*w (feature-sized tensors it must read or write once)
 FWD_KERNEL_E = {"pool": 1, "chan": 1, "apply": 2}
 BWD_KERNEL_E = {"reduce1": 2, "reduce2": 1, "apply": 3}
-KERNEL_SYMBOL = {"fwd.pool": "k_pool", "fwd.chan": "k_chan", "fwd.apply": "k_apply", "fwd.mlp": "k_mlp_fwd",
-                 "fwd.conv": "k_conv_fwd", "bwd.reduce1": "k_bwd_reduce1", "bwd.reduce2": "k_bwd_reduce2",
-                 "bwd.apply": "k_bwd_apply", "bwd.convT": "k_bwd_convT", "bwd.mlp": "k_bwd_mlp", "bwd.finalize": "k_bwd_finalize"}
+KERNEL_SYMBOL = {"fwd.pool": "k_pool", "fwd.chan": "k_chan", "fwd.apply": "k_apply", "bwd.reduce1": "k_bwd_reduce1",
+                 "bwd.reduce2": "k_bwd_reduce2", "bwd.apply": "k_bwd_apply", "bwd.convT": "k_bwd_convT"}
 
 
 def parse():
@@ -94,8 +94,12 @@ def time_kernels(plan, reps):
     import torch
     from mga_yolo_amd import _lib
     out = {}
-    todo = [("fwd." + k, plan.forward, v) for k, v in _lib.FWD_STAGES.items()] + \
-           [("bwd." + k, plan.backward, v) for k, v in _lib.BWD_STAGES.items()]
+    B = _lib.BWD_STAGES
+    todo = [("fwd." + k, plan.forward, v) for k, v in _lib.FWD_STAGES.items()] + [
+        ("bwd.reduce1", plan.backward, B["reduce1"]), ("bwd.convT", plan.backward, B["convT"]),
+        # the two fused launches of the step: streaming workgroups + role workgroups (dWsa partials / parameter gradients)
+        ("bwd.reduce2", plan.backward, B["reduce2"] | B["wsa"] | _lib.BWD_FUSE),
+        ("bwd.apply", plan.backward, B["params"] | B["apply"] | _lib.BWD_FUSE)]
     for name, fn, mask in todo:
         for _ in range(3):
             fn(mask)
@@ -168,24 +172,26 @@ def main():
     plan, desc, batch = make_plan(args.workload, device, seed=1234 + rank)
     exchange = GradExchange(plan.grad_bucket)                    # no-op when world == 1
 
-    def part1():
-        plan.forward()
-        plan.backward_params()
+    S = _lib.FWD_STAGES
 
-    def part2():
-        plan.backward_inputs()
+    def part_a():                # parameter-free prefix of the step: masked pooling
+        plan.forward(S["pool"])
+
+    def part_b():                # everything that reads parameters: rest of forward, whole backward (7 launches/step in all)
+        plan.forward(S["chan"] | S["apply"])
+        plan.backward()
 
     if args.no_graph:
-        run1, run2 = part1, part2
+        run_a, run_b = part_a, part_b
     else:
-        g1, g2 = plan.capture(part1), plan.capture(part2)
-        run1, run2 = g1.replay, g2.replay
+        ga, gb = plan.capture(part_a), plan.capture(part_b)
+        run_a, run_b = ga.replay, gb.replay
 
     def step():
-        run1()                  # forward; backward up to the parameter gradients
-        exchange.start()        # N > 1: all-reduce of the flat gradient bucket on a side stream ...
-        run2()                  # ... overlapped with the input-gradient kernel
-        exchange.finish()
+        run_a()                  # N > 1: overlaps the all-reduce started at the end of the previous step
+        exchange.finish()        # averaged gradients of the previous step are complete before any parameter is read
+        run_b()
+        exchange.start()         # all-reduce of this step's flat gradient bucket on a side stream
 
     def fence():
         torch.cuda.synchronize()
@@ -199,6 +205,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    exchange.finish()            # the last step's exchange is inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -250,7 +257,7 @@ def main():
                     config=dict(workload=desc, batch_per_gpu=batch, global_batch=batch * world,
                                 levels=[list(s) for s in plan.shapes], parallelism=f"dp{world}",
                                 launch="eager" if args.no_graph else "hipGraph replay (2 graphs/step)",
-                                grad_exchange=None if world == 1 else f"RCCL all-reduce of one {plan.grad_bucket.numel() * 4} B bucket, overlapped with k_bwd_apply"),
+                                grad_exchange=None if world == 1 else f"RCCL all-reduce of one {plan.grad_bucket.numel() * 4} B bucket per step, overlapped with the next step's parameter-free k_pool"),
                     roofline=roofline, step_roofline=step_roof, kernels=kernels, cpu_baseline=cpu,
                     lib=_lib.load().mgacbam_build_info().decode())
         print(json.dumps(line))

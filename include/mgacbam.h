@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MGACBAM_ABI_VERSION 1
+#define MGACBAM_ABI_VERSION 4
 #define MGACBAM_MAX_LEVELS 8          /* P3/P4/P5 need 3 */
 
 enum { MGACBAM_F32 = 0, MGACBAM_F16 = 1, MGACBAM_BF16 = 2 };
@@ -128,23 +128,25 @@ int mgacbam_backward(const mgacbam_bwd_level_t* levels, int n_levels, void* stre
  *   - measurement: time one kernel alone with events on `stream` (bench.py roofline).
  * A later stage reads what earlier stages left in ctx / scratch, so both buffers must be kept between calls. */
 enum {
-  MGACBAM_FWD_POOL = 1,      /* masked avg/max pooling over H*W          reads x                    */
-  MGACBAM_FWD_MLP = 2,       /* shared MLP + channel gate                tiny                       */
-  MGACBAM_FWD_CHAN = 4,      /* channel max/mean planes                  reads x                    */
-  MGACBAM_FWD_CONV = 8,      /* k x k conv + spatial gate                tiny                       */
-  MGACBAM_FWD_APPLY = 16,    /* y = x + alpha (x ca sa - x)              reads x, writes y          */
-  MGACBAM_FWD_ALL = 31
+  MGACBAM_FWD_POOL = 1,      /* k_pool : masked avg/max pooling over H*W                      reads x           */
+  MGACBAM_FWD_CHAN = 2,      /* k_chan : shared MLP + channel gate (prologue), channel max/mean planes  reads x */
+  MGACBAM_FWD_APPLY = 4,     /* k_apply: k x k conv + spatial gate (prologue), y = x + alpha (x ca sa - x)      */
+  MGACBAM_FWD_ALL = 7
 };
 enum {
-  MGACBAM_BWD_REDUCE1 = 1,   /* sums of gy*x over H*W and over C         reads x, gy                */
-  MGACBAM_BWD_CONVT = 2,     /* transposed conv + dWsa partials          tiny                       */
-  MGACBAM_BWD_REDUCE2 = 4,   /* rest of dL/dca, dL/dz                    reads x                    */
-  MGACBAM_BWD_MLP = 8,       /* shared-MLP backward                      tiny                       */
-  MGACBAM_BWD_FINALIZE = 16, /* dW1 db1 dW2 db2 dWsa dbeta               tiny                       */
-  MGACBAM_BWD_APPLY = 32,    /* gx (+ gmask)                             reads gy (+x), writes gx   */
-  MGACBAM_BWD_PARAMS = 31,   /* stages the parameter gradients depend on */
-  MGACBAM_BWD_INPUTS = 32,   /* stages only the input gradients depend on */
-  MGACBAM_BWD_ALL = 63
+  MGACBAM_BWD_REDUCE1 = 1,    /* k_bwd_reduce1: sums of gy*x over H*W and over C                reads x, gy       */
+  MGACBAM_BWD_CONVT = 2,      /* k_bwd_convT  : transposed conv -> dL/dplanes                   tiny              */
+  MGACBAM_BWD_REDUCE2 = 4,    /* k_bwd_reduce2: rest of dL/dca, dL/dz, hidden-gradient partials reads x           */
+  MGACBAM_BWD_WSA = 8,        /* k_bwd_wsa    : dWsa tile partials (needs REDUCE1 only)         tiny              */
+  MGACBAM_BWD_PARAMGRAD = 16, /* k_bwd_params : dW1 db1 dW2 db2 dWsa dbeta (needs REDUCE2, WSA) tiny              */
+  MGACBAM_BWD_APPLY = 32,     /* k_bwd_apply  : gx (+ gmask) (needs REDUCE2, CONVT)              reads gy (+x), writes gx */
+  MGACBAM_BWD_FUSE = 64,      /* run WSA as role workgroups inside the REDUCE2 launch and PARAMGRAD inside the APPLY
+                                 launch (when both stages of a pair are requested): the tiny latency-bound kernels then
+                                 overlap the HBM-bound ones instead of standing on the critical path                    */
+  MGACBAM_BWD_PARAMS = 31,    /* every stage the parameter gradients depend on, as separate launches: a data-parallel
+                                 caller starts its all-reduce after this and overlaps it with MGACBAM_BWD_INPUTS     */
+  MGACBAM_BWD_INPUTS = 32,    /* the stage only the input gradients depend on                   */
+  MGACBAM_BWD_ALL = 127       /* everything, fused: what mgacbam_backward() runs                */
 };
 int mgacbam_forward_stages(const mgacbam_fwd_level_t* levels, int n_levels, int stages, void* stream);
 int mgacbam_backward_stages(const mgacbam_bwd_level_t* levels, int n_levels, int stages, void* stream);

@@ -8,13 +8,14 @@ import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmgacbam.so")
-ABI_VERSION = 1
+ABI_VERSION = 4
 MAX_LEVELS = 8
 F32, F16, BF16 = 0, 1, 2
 # stage bit masks (include/mgacbam.h)
-FWD_STAGES = dict(pool=1, mlp=2, chan=4, conv=8, apply=16)
-BWD_STAGES = dict(reduce1=1, convT=2, reduce2=4, mlp=8, finalize=16, apply=32)
-FWD_ALL, BWD_PARAMS, BWD_INPUTS, BWD_ALL = 31, 31, 32, 63
+FWD_STAGES = dict(pool=1, chan=2, apply=4)
+BWD_STAGES = dict(reduce1=1, convT=2, reduce2=4, wsa=8, params=16, apply=32)
+BWD_FUSE = 64
+FWD_ALL, BWD_PARAMS, BWD_INPUTS, BWD_ALL = 7, 31, 32, 127
 
 _c_float_p = C.POINTER(C.c_float)
 

@@ -30,8 +30,11 @@ struct Tune {
   int apply_tx;    // k_apply
   int apply_cpt;
   int chan_tx;     // k_chan / k_bwd_reduce1 / k_bwd_apply : one H*W vector per lane, TY = 256/TX channel slices
-  int conv_twq;    // conv tiles: TWQ quads (4 px) wide, TH rows
+  int conv_twq;    // backward conv tiles: TWQ quads (4 px) wide, TH rows
   int conv_th;
+  int wsa_th;      // k_bwd_wsa tiles: fewer rows so 4 staged planes stay under ~16 KB of LDS (role workgroups)
+  int apply_rows;  // k_apply: upper bound of the plane rows (tile rows + halo) staged per workgroup
+  int nt_stores;   // 1: y / gx are written with non-temporal stores
 };
 
 struct FwdArgs {
@@ -51,7 +54,8 @@ struct ScratchPtrs {
   float* gh_avg;    // (B,hidden)
   float* gh_mx;     // (B,hidden)
   float* chan4;     // (B,C,4)   {ca, g_avg, g_mx at arg-max, g_mx / N when GAP fallback}
-  float* Kb;        // (B)       sum_c g_avg * mavg * [S >= eps]
+  float* Kb;        // (B)       (unused since v3)
+  float* pgh;       // (B,ncg,hidden) per-channel-group partials of W2^T g_z (k_bwd_reduce2 -> k_bwd_apply prologue)
 };
 
 struct BwdArgs {
@@ -59,8 +63,10 @@ struct BwdArgs {
   float* gw1; float* gb1; float* gw2; float* gb2; float* gwsa; float* gbeta;
   CtxPtrs c; ParamPtrs p; ScratchPtrs s; Geo g; Tune t;
   int nt;       // hw tiles of k_bwd_reduce1
-  int nconv;    // conv tiles of this level (B * tiles_y * tiles_x): one dWsa partial each
-  int r2_blocks;// workgroups of the streaming part of k_bwd_reduce2 (the dWsa role blocks follow them)
+  int nconv;    // k_bwd_convT tiles of this level (B * tiles_y * tiles_x)
+  int nwsa;     // k_bwd_wsa tiles of this level: one dWsa partial each
+  int npg;      // parameter-gradient workgroups of this level (k_bwd_params roles)
+  int ncg;      // channel groups per sample of k_bwd_reduce2
 };
 
 static inline size_t align16(size_t v) { return (v + 15) & ~size_t(15); }

@@ -4,20 +4,20 @@
 // With a = softplus(beta), u = x*ca, v = u*sa, N = H*W:
 //   k_bwd_reduce1  x, gy (1 read each) -> A[b,c] = sum_hw gy*x*sa, Q[b,c] = sum_hw gy*x   (per hw-tile partials)
 //                                         g_pre[b,hw] = a * sa(1-sa) * sum_c ca*gy*x
-//   k_bwd_convT    g_pre, planes       -> g_planes = conv_transpose(g_pre, Wsa) ; per-workgroup partials of dWsa
+//   k_bwd_convT    g_pre, planes       -> g_planes = conv_transpose(g_pre, Wsa) ; per-tile partials of dWsa     [tiny]
 //   k_bwd_reduce2  x (1 read)          -> g_ca[b,c] = a*A + sum_hw x * ([c == cidx]*gp0 + gp1/C) ; g_z ; (ca*A - Q)
-//   k_bwd_mlp      g_z                 -> g_h*, g_avg, g_mx (shared-MLP backward for both descriptors), K_b
-//   k_bwd_apply    gy (+ x when dL/dmask is wanted) -> gx (1 write), gmask
-//   k_bwd_finalize per-sample / per-workgroup partials -> dW1, db1, dW2, db2, dWsa, dbeta
+//   k_bwd_params   g_z, partials       -> dW1 db1 dW2 db2 dWsa dbeta and g_h (relu-masked) per sample            [tiny]
+//   k_bwd_apply    gy (+ x when dL/dmask is wanted) -> prologue: g_avg, g_mx = W1^T g_h ; body: gx (1 write), gmask
 //
 // Algebra that keeps traffic at 2+1+3 passes: the term of g_ca that needs g_planes only needs x (not gy),
 // and gx needs gy, the saved arg-max indices and planes but x only for the masked-average part of dL/dmask.
 // All cross-workgroup sums are two-stage (partials, then one reader), never float atomics, so results are
-// bitwise reproducible run to run.
+// bitwise reproducible run to run.  Every parameter gradient is complete after k_bwd_params, i.e. BEFORE the
+// largest kernel (k_bwd_apply) runs, so a data-parallel all-reduce of them overlaps it.
 #pragma once
 #include "args.cuh"
 #include "common.cuh"
-#include "fwd.cuh"   // ConvTile / stage_tiles
+#include "fwd.cuh"   // ConvTile / stage_window
 
 namespace mgacbam {
 
@@ -96,34 +96,35 @@ __global__ __launch_bounds__(kBlock) void k_bwd_reduce1(const Group<BwdArgs> G) 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_bwd_convT: g_planes[p] = sum_{i,j} W[p,i,j] * g_pre[h-i+pad, w-j+pad]   (transposed conv, flipped kernel)
-//   same tiling as k_conv_fwd; LDS holds the g_pre tile + halo; 4 adjacent pixels x 3 planes per thread.
+// k_bwd_convT: g_planes[p] = sum_{i,j} W[p,i,j] * g_pre[h-i+pad, w-j+pad]   (transposed conv = correlation with the
+//   flipped kernel).  Tile = TH rows x TW columns of one sample, g_pre tile + halo in LDS (one load batch), 4 adjacent
+//   pixels x 3 planes per thread.  On the critical path between k_bwd_reduce1 and k_bwd_reduce2, so it does nothing else.
 // ---------------------------------------------------------------------------------------------
 template <int K>
 __global__ __launch_bounds__(kBlock) void k_bwd_convT(const Group<BwdArgs> G) {
-  extern __shared__ float smem[];
+  extern __shared__ __align__(16) float smem[];
   int local;
   const int lvl = find_level(G, blockIdx.x, local);
   const BwdArgs& A = G.lv[lvl];
   const Geo& g = A.g;
   const int k = K ? K : g.k;
-  const ConvTile c = conv_tile(g, A.t, k, local);
+  const ConvTile c = conv_tile(g, A.t, k, local, A.t.conv_th);
   const int tid = threadIdx.x;
   float* wts = smem;
-  float* tg = smem + ((3 * k * k + 3) & ~3);
+  float* tg = smem + ((3 * k * k + 3) & ~3);   // g_pre tile + halo
   for (int i = tid; i < 3 * k * k; i += kBlock) wts[i] = A.p.wsa[i];
   const float* gpre = A.s.gpre + static_cast<size_t>(c.b) * g.HW;
-  stage_tiles<1>(tg, c, g, [&](int) { return gpre; });
+  stage_window<8>(tg, 1, c.PH, c.PW, c.y0 - c.pad, c.x0 - c.pad, g, [&](int) { return gpre; });
   __syncthreads();
   const int TWQ = A.t.conv_twq;
   const int py = tid / TWQ, q = tid - py * TWQ;
+  constexpr int KK = K ? K : 1;
   if (py >= c.TH) return;
   float acc[3][4];
 #pragma unroll
   for (int p = 0; p < 3; ++p)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[p][e] = 0.f;
-  constexpr int KK = K ? K : 1;
   if (K) {
 #pragma unroll 1
     for (int i = 0; i < KK; ++i) {
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_convT(const Group<BwdArgs> G) {
       for (int t = 0; t < 4 + KK - 1; ++t) r[t] = row[t];
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
-        const float* wr = wts + (p * KK + (KK - 1 - i)) * KK;               // flipped kernel row
+        const float* wr = wts + (p * KK + (KK - 1 - i)) * KK;             // flipped kernel row
 #pragma unroll
         for (int j = 0; j < KK; ++j) {
           const float wv = wr[KK - 1 - j];
@@ -170,42 +171,85 @@ __global__ __launch_bounds__(kBlock) void k_bwd_convT(const Group<BwdArgs> G) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// dWsa partial of one conv tile:  sum_{px in tile} g_pre[px] * planes[p][px + (i,j) - pad]
-//   thread t < 3*k*k owns output (p,i,j) and walks the tile's pixels (LDS only).  This is LDS/VALU work with no
-//   HBM traffic, so these workgroups ride in front of the HBM-bound k_bwd_reduce2 grid ("role" blocks) and
-//   overlap with it instead of costing a launch of their own.
+// k_bwd_wsa: per conv tile, the partial of dWsa[p,i,j] = sum_px g_pre[px] * planes[p][px + (i,j) - pad].
+//   Needs only g_pre and the forward planes and feeds only k_bwd_params, so it is OFF the critical path: a graph /
+//   multi-stream caller runs it beside k_bwd_reduce2 (PyramidPlan does).  g_pre and the 3 planes (tile + halo) are
+//   staged in LDS in one load batch; work item = (p, i, tile row): it slides a k-wide register window along the row,
+//   so each LDS value feeds k FMAs (one g_pre and one plane read per pixel for k outputs); the rows are then summed
+//   through LDS.  K == 0 (any odd k): one thread per output.
+//   LDS: [g_pre tile][3 plane tiles][items * k partial sums]
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bwd_wsa_body(const BwdArgs& A, const int bid, float* tile) {
+template <int K>
+__device__ __forceinline__ void bwd_wsa_body(const BwdArgs& A, const int local, float* smem) {
   const Geo& g = A.g;
-  const int k = g.k;
-  const ConvTile c = conv_tile(g, A.t, k, bid);
+  const int k = K ? K : g.k;
+  const ConvTile c = conv_tile(g, A.t, k, local, A.t.wsa_th);
+  const int tid = threadIdx.x;
   const int plane_elems = c.PH * c.PW;
-  float* tg = tile;                      // g_pre tile + halo
-  float* tp = tile + plane_elems;        // 3 plane tiles + halo
+  float* tg = smem;                            // g_pre tile + halo
+  float* tp = tg + plane_elems;                // 3 plane tiles + halo
+  float* accs = tp + 3 * plane_elems;          // (3*k*TH) x k row partials
   const float* gpre = A.s.gpre + static_cast<size_t>(c.b) * g.HW;
   const float* pl = A.c.planes + static_cast<size_t>(c.b) * 3 * g.HW;
-  stage_tiles<4>(tile, c, g, [&](int p) { return p == 0 ? gpre : pl + static_cast<size_t>(p - 1) * g.HW; });
+  stage_window<8>(tg, 4, c.PH, c.PW, c.y0 - c.pad, c.x0 - c.pad, g,
+                   [&](int p) { return p == 0 ? gpre : pl + static_cast<size_t>(p - 1) * g.HW; });
   __syncthreads();
+  constexpr int KK = K ? K : 1;
   const int nout = 3 * k * k;
-  for (int o = threadIdx.x; o < nout; o += kBlock) {
-    const int p = o / (k * k), r = o - p * k * k;
-    const int i = r / k, j = r - i * k;
-    const float* pp = tp + p * plane_elems + i * c.PW + j;      // planes[p][y + i - pad][x + j - pad]
-    const float* gg = tg + c.pad * c.PW + c.pad;                // g_pre[y][x]
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int yy = 0; yy < c.TH; ++yy) {
-      const float* prow = pp + yy * c.PW;
-      const float* grow = gg + yy * c.PW;
-#pragma unroll 4
-      for (int xx = 0; xx < c.TW; xx += 4) {                    // TW is a multiple of 4; zero fill outside the image
-        a0 += grow[xx] * prow[xx];
-        a1 += grow[xx + 1] * prow[xx + 1];
-        a2 += grow[xx + 2] * prow[xx + 2];
-        a3 += grow[xx + 3] * prow[xx + 3];
+  if (K) {
+    const int nitems = 3 * KK * c.TH;                            // (p, i, row)
+    for (int item = tid; item < nitems; item += kBlock) {
+      const int pi = item / c.TH, r = item - pi * c.TH;          // pi = p*K + i
+      const int p = pi / KK, i = pi - p * KK;
+      const float* prow = tp + p * plane_elems + (r + i) * c.PW;           // planes[p][y0 + r + i - pad][x0 - pad + ...]
+      const float* grow = tg + (r + c.pad) * c.PW + c.pad;                 // g_pre[y0 + r][x0 + ...]
+      float acc[KK];
+#pragma unroll
+      for (int j = 0; j < KK; ++j) acc[j] = 0.f;
+      float w[KK + 3];
+#pragma unroll
+      for (int t = 0; t < KK - 1; ++t) w[t] = prow[t];
+      for (int x = 0; x < c.TW; x += 4) {                        // TW is a multiple of 4; zeros outside the image
+        float gq[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gq[e] = grow[x + e]; w[KK - 1 + e] = prow[x + KK - 1 + e]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int j = 0; j < KK; ++j) acc[j] += gq[e] * w[e + j];
+#pragma unroll
+        for (int t = 0; t < KK - 1; ++t) w[t] = w[t + 4];
       }
+#pragma unroll
+      for (int j = 0; j < KK; ++j) accs[item * KK + j] = acc[j];
     }
-    A.s.gwsa_part[static_cast<size_t>(o) * A.nconv + bid] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    for (int o = tid; o < nout; o += kBlock) {                   // o = (p*K + i)*K + j
+      const int pi = o / KK, j = o - pi * KK;
+      float sum = 0.f;
+      for (int r = 0; r < c.TH; ++r) sum += accs[(pi * c.TH + r) * KK + j];
+      A.s.gwsa_part[static_cast<size_t>(o) * A.nwsa + local] = sum;
+    }
+  } else {
+    for (int o = tid; o < nout; o += kBlock) {
+      const int p = o / (k * k), r = o - p * k * k;
+      const int i = r / k, j = r - i * k;
+      const float* pp = tp + p * plane_elems + i * c.PW + j;
+      const float* gg = tg + c.pad * c.PW + c.pad;
+      float sum = 0.f;
+      for (int yy = 0; yy < c.TH; ++yy)
+        for (int xx = 0; xx < c.TW; ++xx) sum += gg[yy * c.PW + xx] * pp[yy * c.PW + xx];
+      A.s.gwsa_part[static_cast<size_t>(o) * A.nwsa + local] = sum;
+    }
   }
+}
+
+template <int K>
+__global__ __launch_bounds__(kBlock) void k_bwd_wsa(const Group<BwdArgs> G) {
+  extern __shared__ __align__(16) float smem[];
+  int local;
+  const int lvl = find_level(G, blockIdx.x, local);
+  bwd_wsa_body<K>(G.lv[lvl], local, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -256,7 +300,19 @@ __device__ __forceinline__ void bwd_reduce2_body(const BwdArgs& A, const int bid
       }
     }
   }
-  row_sum<CPT>(acc, TX, tid, red);
+  // the hw-tile partials of k_bwd_reduce1 are summed by the same row reduction (lanes stride the tiles)
+  float sums[3 * CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const size_t o = (static_cast<size_t>(b) * g.C + cj[j]) * A.nt;
+    float As = 0.f, Qs = 0.f;
+    for (int t = tx; t < A.nt; t += TX) { As += A.s.A_part[o + t]; Qs += A.s.Q_part[o + t]; }
+    sums[j] = acc[j]; sums[CPT + j] = As; sums[2 * CPT + j] = Qs;
+  }
+  row_sum<3 * CPT>(sums, TX, tid, red);
+  float gzv[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) gzv[j] = 0.f;                  // channels past C contribute nothing
   if (tx == 0) {
     const float a = softplusf_(*A.p.beta);
 #pragma unroll
@@ -264,86 +320,168 @@ __device__ __forceinline__ void bwd_reduce2_body(const BwdArgs& A, const int bid
       const int c = c0 + j;
       if (c < g.C) {
         const size_t o = static_cast<size_t>(b) * g.C + c;
-        float As = 0.f, Qs = 0.f;
-        for (int t = 0; t < A.nt; ++t) { As += A.s.A_part[o * A.nt + t]; Qs += A.s.Q_part[o * A.nt + t]; }
+        const float As = sums[CPT + j], Qs = sums[2 * CPT + j];
         const float ca = A.c.ca[o];
-        const float gca = a * As + acc[j];
-        A.s.gz[o] = gca * ca * (1.f - ca);
+        const float gca = a * As + sums[j];
+        gzv[j] = gca * ca * (1.f - ca);
+        A.s.gz[o] = gzv[j];
         A.s.gbq[o] = ca * As - Qs;                             // sum_hw gy*(v - x) for this (b,c)
       }
     }
   }
-}
-
-// grid of a level = [nconv dWsa role workgroups][streaming workgroups]
-template <typename T, int VEC, int CPT>
-__global__ __launch_bounds__(kBlock) void k_bwd_reduce2(const Group<BwdArgs> G) {
-  extern __shared__ float smem[];       // role blocks: 4 conv tiles; streaming blocks: 64 floats of reduction scratch
-  int local;
-  const int l = find_level(G, blockIdx.x, local);
-  const BwdArgs& A = G.lv[l];
-  if (local < A.nconv) bwd_wsa_body(A, local, smem);
-  else bwd_reduce2_body<T, VEC, CPT>(A, local - A.nconv, smem);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_bwd_mlp: backward of the shared MLP for both applications (inputs avg and mx); one workgroup per sample
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_bwd_mlp(const Group<BwdArgs> G) {
-  extern __shared__ float sm[];
-  __shared__ float red[8];
-  int local;
-  const int lvl = find_level(G, blockIdx.x, local);
-  const BwdArgs& A = G.lv[lvl];
-  const Geo& g = A.g;
-  const int b = local, tid = threadIdx.x, C = g.C, h = g.hidden;
-  float* s_gz = sm;           // C
-  float* s_ga = sm + C;       // h  gh_avg
-  float* s_gm = s_ga + h;     // h  gh_mx
-  for (int c = tid; c < C; c += kBlock) s_gz[c] = A.s.gz[static_cast<size_t>(b) * C + c];
-  __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63;
-  for (int j = wave; j < h; j += kBlock / kWave) {
-    float d = 0.f;
-    for (int c = lane; c < C; c += kWave) d += A.p.w2[static_cast<size_t>(c) * h + j] * s_gz[c];
-    d = wave_group_sum(d, kWave);
-    if (lane == 0) {
-      const float ga = A.c.h_avg[static_cast<size_t>(b) * h + j] > 0.f ? d : 0.f;   // relu backward
-      const float gm = A.c.h_mx[static_cast<size_t>(b) * h + j] > 0.f ? d : 0.f;
-      s_ga[j] = ga; s_gm[j] = gm;
-      A.s.gh_avg[static_cast<size_t>(b) * h + j] = ga;
-      A.s.gh_mx[static_cast<size_t>(b) * h + j] = gm;
+  // this workgroup's share of the hidden gradient: pgh[b,cg,j] = sum_{c in group} W2[c,j] * g_z[b,c]
+  // (k_bwd_apply sums the groups in its prologue, so it does not wait for the parameter-gradient kernel)
+  const int h = g.hidden;
+  float* s_pg = red + 64;                                      // TY x h
+  if (tx == 0) {
+    for (int jh = 0; jh < h; ++jh) {
+      float p = 0.f;
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) p += A.p.w2[static_cast<size_t>(cj[j]) * h + jh] * gzv[j];
+      s_pg[ty * h + jh] = p;
     }
   }
   __syncthreads();
-  const float N = static_cast<float>(g.HW);
-  const bool has_mask = A.mask != nullptr;
-  const float live = (has_mask && A.c.S[b] >= g.eps) ? 1.f : 0.f;   // clamp_min passes grad only when not clamped
-  float kpart = 0.f;
-  for (int c = tid; c < C; c += kBlock) {
-    float ga = 0.f, gm = 0.f;
-    for (int j = 0; j < h; ++j) { const float wv = A.p.w1[static_cast<size_t>(j) * C + c]; ga += wv * s_ga[j]; gm += wv * s_gm[j]; }
-    const size_t o = static_cast<size_t>(b) * C + c;
-    const int valid = A.c.valid[o];
-    float4 q;
-    q.x = A.c.ca[o];
-    q.y = ga;                               // g_avg
-    q.z = valid ? gm : 0.f;                 // routed to the arg-max position
-    q.w = valid ? 0.f : gm / N;             // GAP fallback: spread uniformly
-    reinterpret_cast<float4*>(A.s.chan4)[o] = q;
-    kpart += ga * A.c.mavg[o] * live;
+  for (int jh = tid; jh < h; jh += kBlock) {
+    float p = 0.f;
+    for (int r = 0; r < TY; ++r) p += s_pg[r * h + jh];
+    A.s.pgh[(static_cast<size_t>(b) * ncg + cg) * h + jh] = p;
   }
-  kpart = block_sum(kpart, tid, red);
-  if (tid == 0) A.s.Kb[b] = kpart;
+}
+
+// ROLES: the level's grid is [nwsa dWsa-partial workgroups (k = 7)][streaming workgroups]: the LDS/VALU-bound role
+// workgroups are dispatched first and overlap with the HBM-bound ones instead of costing a launch on the critical path.
+template <typename T, int VEC, int CPT, bool ROLES>
+__global__ __launch_bounds__(kBlock) void k_bwd_reduce2(const Group<BwdArgs> G) {
+  extern __shared__ __align__(16) float smem[];                // [64 reduction scratch][TY * hidden] | wsa tiles
+  int local;
+  const int l = find_level(G, blockIdx.x, local);
+  const BwdArgs& A = G.lv[l];
+  if (ROLES) {
+    if (local < A.nwsa) { bwd_wsa_body<7>(A, local, smem); return; }
+    local -= A.nwsa;
+  }
+  bwd_reduce2_body<T, VEC, CPT>(A, local, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_bwd_params: every parameter gradient + the relu-masked hidden gradients, one launch.  Workgroup roles in a level:
+//   [0, h)            hidden unit j: g_h[b,j] = sum_c W2[c,j] g_z[b,c] for all b (masked by relu for the avg / mx
+//                     application) -> gh_avg, gh_mx ; dW1[j,:], db1[j], dW2[:,j]          (shared MLP used twice)
+//   [h, h+nb2)        db2[c] = 2 sum_b g_z[b,c]
+//   [.., +nb_wsa)     dWsa[p,i,j] = sum over conv tiles of the partials (one wave per output)
+//   last              dbeta = sigmoid(beta) * sum_{b,c} (ca*A - Q)
+//   LDS (dynamic): 3*B floats
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bwd_params_body(const BwdArgs& A, const int local, float* sm, float* red) {
+  const Geo& g = A.g;
+  const int C = g.C, h = g.hidden, B = g.B, kk3 = 3 * g.k * g.k;
+  const int nb2 = (C + kBlock - 1) / kBlock, nb_wsa = (kk3 + 3) / 4;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (local < h) {
+    const int j = local;
+    float* s_ga = sm; float* s_gm = sm + B; float* s_hs = sm + 2 * B;   // 3*B
+    float* s_part = sm + 3 * B;                                         // 2 * kBlock (b-group partials of dW1, dW2)
+    // phase A: g_h[b,j] for every sample (one wave per sample, 4 samples in flight per workgroup)
+#pragma unroll 2
+    for (int b = wave; b < B; b += kBlock / kWave) {
+      const float* gz = A.s.gz + static_cast<size_t>(b) * C;
+      float d = 0.f;
+#pragma unroll 4
+      for (int c = lane; c < C; c += kWave) d += A.p.w2[static_cast<size_t>(c) * h + j] * gz[c];
+      d = wave_group_sum(d, kWave);
+      if (lane == 0) {
+        const float ha = A.c.h_avg[b * h + j], hm = A.c.h_mx[b * h + j];
+        const float ga = ha > 0.f ? d : 0.f, gm = hm > 0.f ? d : 0.f;          // relu backward
+        s_ga[b] = ga; s_gm[b] = gm; s_hs[b] = ha + hm;
+        A.s.gh_avg[b * h + j] = ga;
+        A.s.gh_mx[b * h + j] = gm;
+      }
+    }
+    __syncthreads();
+    // phase B: dW1[j,c] and dW2[c,j]: thread = (channel, sample group); groups combined through LDS in fixed order
+    const int cp = (C >= kBlock) ? kBlock : C;                   // channels handled per pass
+    const int ng = kBlock / cp;                                  // sample groups (1 when C >= 256)
+    const int cl = tid % cp, bg = tid / cp;
+    for (int c0 = 0; c0 < C; c0 += cp) {
+      const int c = c0 + cl;
+      float w1 = 0.f, w2 = 0.f;
+      if (c < C && bg < ng) {
+#pragma unroll 4
+        for (int b = bg; b < B; b += ng) {
+          const size_t o = static_cast<size_t>(b) * C + c;
+          w1 += s_ga[b] * A.c.avg[o] + s_gm[b] * A.c.mx[o];                    // dW1[j,c]
+          w2 += A.s.gz[o] * s_hs[b];                                           // dW2[c,j]
+        }
+      }
+      if (ng > 1) {
+        __syncthreads();
+        s_part[tid] = w1; s_part[kBlock + tid] = w2;
+        __syncthreads();
+        if (bg == 0 && c < C) {
+          for (int q = 1; q < ng; ++q) { w1 += s_part[q * cp + cl]; w2 += s_part[kBlock + q * cp + cl]; }
+        }
+      }
+      if (bg == 0 && c < C) {
+        A.gw1[static_cast<size_t>(j) * C + c] = w1;
+        A.gw2[static_cast<size_t>(c) * h + j] = w2;
+      }
+    }
+    if (tid == 0) {
+      float acc = 0.f;
+      for (int b = 0; b < B; ++b) acc += s_ga[b] + s_gm[b];
+      A.gb1[j] = acc;
+    }
+    return;
+  }
+  if (local < h + nb2) {                                         // db2[c] = 2 * sum_b g_z[b,c]   (bias used twice)
+    const int c = (local - h) * kBlock + tid;
+    if (c >= C) return;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < B; ++b) acc += A.s.gz[static_cast<size_t>(b) * C + c];
+    A.gb2[c] = 2.f * acc;
+    return;
+  }
+  if (local < h + nb2 + nb_wsa) {                                // dWsa: lanes stride the tile partials
+    const int o = (local - h - nb2) * 4 + wave;
+    if (o >= kk3) return;
+    const float* part = A.s.gwsa_part + static_cast<size_t>(o) * A.nwsa;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int t = lane; t < A.nwsa; t += kWave) acc += part[t];
+    acc = wave_group_sum(acc, kWave);
+    if (lane == 0) A.gwsa[o] = acc;
+    return;
+  }
+  {                                                              // dbeta
+    float acc = 0.f;
+#pragma unroll 8
+    for (int o = tid; o < B * C; o += kBlock) acc += A.s.gbq[o];
+    acc = block_sum(acc, tid, red);
+    if (tid == 0) *A.gbeta = sigmoidf_(*A.p.beta) * acc;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_bwd_params(const Group<BwdArgs> G) {
+  extern __shared__ __align__(16) float sm[];
+  __shared__ float red[8];
+  int local;
+  const int lvl = find_level(G, blockIdx.x, local);
+  bwd_params_body(G.lv[lvl], local, sm, red);
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_bwd_apply       (thread layout of k_chan)
 //   gx = gy*((1-a) + a*sa*ca) + ca*([c==cidx]*gp0 + gp1/C) + g_avg*wA + [hw==amax]*g_mx_pt + g_mx_uni
 //   gmask = (gp2 + (use/den) * (sum_c g_avg*x - K_b)) * s(1-s)
+//   Prologue (per workgroup, for its sample): g_avg = W1^T gh_avg, g_mx = W1^T gh_mx -> q[c] = {ca, g_avg, g_mx routed to
+//   the arg-max position, g_mx/N for the GAP fallback} in LDS, and K_b = sum_c g_avg * mavg * [S >= eps].
+//   LDS: [C float4 q][2*hidden][256*VEC combine]
 // ---------------------------------------------------------------------------------------------
 template <typename T, int VEC, bool GMASK>
-__device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, float* sm) {
+__device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, float* smem, float* red) {
+  constexpr int UN = 2;
   const Geo& g = A.g;
   const int tid = threadIdx.x;
   const int TX = A.t.chan_tx, lt = ilog2(TX);
@@ -378,18 +516,71 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
     sav[e] *= a;                                              // a*sa
     wA[e] = has_mask ? (use * sv[e] / den + (1.f - use) / N) : 1.f / N;
   }
-  const float4* ch4 = reinterpret_cast<const float4*>(A.s.chan4) + static_cast<size_t>(b) * g.C;
   const int* amax = A.c.amax + static_cast<size_t>(b) * g.C;
   float accp[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) accp[e] = 0.f;
 
-#pragma unroll 4
-  for (int c = ty; c < g.C; c += TY) {
-    float gv[VEC], xv[VEC], ov[VEC];
-    load_vec<T, VEC>(gp + static_cast<size_t>(c) * g.HW, gv);
-    if (GMASK) load_vec<T, VEC>(xp + static_cast<size_t>(c) * g.HW, xv);
-    const float4 q = ch4[c];
+  // first feature vectors are requested before the prologue so its latency overlaps theirs
+  float g0v[UN][VEC], x0v[UN][VEC];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const size_t co = static_cast<size_t>(min(ty + u * TY, g.C - 1)) * g.HW;
+    load_vec<T, VEC>(gp + co, g0v[u]);
+    if (GMASK) load_vec<T, VEC>(xp + co, x0v[u]);
+  }
+
+  // ---- prologue: q[c] and K_b for this sample -------------------------------------------------------------------
+  float4* s_q = reinterpret_cast<float4*>(smem);
+  float* s_gh = smem + 4 * g.C;
+  float* sm = s_gh + 2 * g.hidden;
+  const int h = g.hidden;
+  const float live = (has_mask && A.c.S[b] >= g.eps) ? 1.f : 0.f;   // clamp_min passes grad only when not clamped
+  float kpart = 0.f;
+  {
+    // hidden gradient of this sample: g_h[j] = sum over channel groups of k_bwd_reduce2's partials (fixed order),
+    // relu-masked for the two applications of the shared MLP
+    const float* pg = A.s.pgh + static_cast<size_t>(b) * A.ncg * h;
+    const int hh = h < kBlock ? h : kBlock;
+    const int G_ = kBlock / hh;                                  // threads per hidden unit
+    const int j0 = tid % hh, k0 = tid / hh;
+    for (int jb = 0; jb < h; jb += hh) {                         // one pass unless hidden > 256
+      const int j = jb + j0;
+      float p = 0.f;
+      if (k0 < G_ && j < h)
+        for (int cg = k0; cg < A.ncg; cg += G_) p += pg[cg * h + j];
+      sm[tid] = p;
+      __syncthreads();
+      if (k0 == 0 && j < h) {
+        for (int q = 1; q < G_; ++q) p += sm[q * hh + j0];
+        s_gh[j] = A.c.h_avg[static_cast<size_t>(b) * h + j] > 0.f ? p : 0.f;
+        s_gh[h + j] = A.c.h_mx[static_cast<size_t>(b) * h + j] > 0.f ? p : 0.f;
+      }
+      __syncthreads();
+    }
+  }
+  for (int c = tid; c < g.C; c += kBlock) {
+    float ga = 0.f, gm = 0.f;
+    for (int j = 0; j < h; ++j) { const float wv = A.p.w1[static_cast<size_t>(j) * g.C + c]; ga += wv * s_gh[j]; gm += wv * s_gh[h + j]; }
+    const size_t o = static_cast<size_t>(b) * g.C + c;
+    const int valid = A.c.valid[o];
+    float4 q;
+    q.x = A.c.ca[o];
+    q.y = ga;
+    q.z = valid ? gm : 0.f;
+    q.w = valid ? 0.f : gm / N;
+    s_q[c] = q;
+    kpart += ga * A.c.mavg[o] * live;
+  }
+
+  kpart = block_sum(kpart, tid, red);       // (contains the barriers that publish s_q)
+  if (tid == 0) red[7] = kpart;
+  __syncthreads();
+  const float kb = red[7];
+
+  auto emit = [&](const float (&gv)[VEC], const float (&xv)[VEC], int c) {
+    float ov[VEC];
+    const float4 q = s_q[c];
     const int am = amax[c] - ii * VEC;                        // offset of the arg-max inside this vector, if any
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -400,7 +591,19 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
       ov[e] = r;
       if (GMASK) accp[e] += q.y * xv[e];
     }
-    if (active) store_vec<T, VEC>(op + static_cast<size_t>(c) * g.HW, ov);
+    if (active) store_vec_stream<T, VEC>(op + static_cast<size_t>(c) * g.HW, ov, A.t.nt_stores);
+  };
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const int c = ty + u * TY;
+    if (c < g.C) emit(g0v[u], x0v[u], c);
+  }
+#pragma unroll 4
+  for (int c = ty + UN * TY; c < g.C; c += TY) {
+    float gv[VEC], xv[VEC];
+    load_vec<T, VEC>(gp + static_cast<size_t>(c) * g.HW, gv);
+    if (GMASK) load_vec<T, VEC>(xp + static_cast<size_t>(c) * g.HW, xv);
+    emit(gv, xv, c);
   }
   if (GMASK) {
 #pragma unroll
@@ -414,7 +617,6 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
       }
       float g2[VEC], gm[VEC];
       load_vec<float, VEC>(A.s.gplanes + (static_cast<size_t>(b) * 3 + 2) * g.HW + static_cast<size_t>(i) * VEC, g2);
-      const float kb = A.s.Kb[b];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const float gs = g2[e] + (use / den) * (accp[e] - kb);
@@ -425,84 +627,20 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
   }
 }
 
-template <typename T, int VEC, bool GMASK>
+// ROLES: the level's grid is [npg parameter-gradient workgroups][streaming workgroups]; the tiny, latency-bound
+// parameter kernel hides behind the largest kernel of the step instead of standing alone on the critical path.
+template <typename T, int VEC, bool GMASK, bool ROLES>
 __global__ __launch_bounds__(kBlock) void k_bwd_apply(const Group<BwdArgs> G) {
-  __shared__ float sm[kBlock * VEC];
-  int local;
-  const int l = find_level(G, blockIdx.x, local);
-  bwd_apply_body<T, VEC, GMASK>(G.lv[l], local, sm);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_bwd_finalize: parameter gradients from per-sample / per-tile partials (one reader per output, fixed order)
-//   workgroup roles inside a level: [0, nb_mlp) thread-per-output over dW1 (h*C), db1 (h), dW2 (C*h), db2 (C),
-//   each a sum over the B samples; [nb_mlp, nb_mlp + nb_wsa) wave-per-output over the nconv dWsa partials;
-//   last workgroup: dbeta = sigmoid(beta) * sum_{b,c} (ca*A - Q).
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_bwd_finalize(const Group<BwdArgs> G) {
+  extern __shared__ __align__(16) float smem[];
   __shared__ float red[8];
   int local;
-  const int lvl = find_level(G, blockIdx.x, local);
-  const BwdArgs& A = G.lv[lvl];
-  const Geo& g = A.g;
-  const int C = g.C, h = g.hidden, B = g.B, kk3 = 3 * g.k * g.k;
-  const int n_w1 = h * C, n_b1 = h, n_w2 = C * h, n_b2 = C;
-  const int total = n_w1 + n_b1 + n_w2 + n_b2;
-  const int nb_mlp = (total + kBlock - 1) / kBlock;
-  const int nb_wsa = (kk3 + 3) / 4;
-  const int tid = threadIdx.x;
-  if (local >= nb_mlp + nb_wsa) {                              // dbeta
-    float acc = 0.f;
-    for (int o = tid; o < B * C; o += kBlock) acc += A.s.gbq[o];
-    acc = block_sum(acc, tid, red);
-    if (tid == 0) *A.gbeta = sigmoidf_(*A.p.beta) * acc;
-    return;
+  const int l = find_level(G, blockIdx.x, local);
+  const BwdArgs& A = G.lv[l];
+  if (ROLES) {
+    if (local < A.npg) { bwd_params_body(A, local, smem, red); return; }
+    local -= A.npg;
   }
-  if (local >= nb_mlp) {                                       // dWsa[p,i,j] = sum over conv tiles (lanes stride the partials)
-    const int o = (local - nb_mlp) * 4 + (tid >> 6), lane = tid & 63;
-    if (o >= kk3) return;
-    const float* part = A.s.gwsa_part + static_cast<size_t>(o) * A.nconv;
-    float acc = 0.f;
-    for (int t = lane; t < A.nconv; t += kWave) acc += part[t];
-    acc = wave_group_sum(acc, kWave);
-    if (lane == 0) A.gwsa[o] = acc;
-    return;
-  }
-  int o = local * kBlock + tid;
-  if (o >= total) return;
-  if (o < n_w1) {                                              // dW1[j,c] = sum_b gh_avg[b,j]*avg[b,c] + gh_mx[b,j]*mx[b,c]
-    const int j = o / C, c = o - j * C;
-    float acc = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < B; ++b)
-      acc += A.s.gh_avg[b * h + j] * A.c.avg[static_cast<size_t>(b) * C + c] + A.s.gh_mx[b * h + j] * A.c.mx[static_cast<size_t>(b) * C + c];
-    A.gw1[o] = acc;
-    return;
-  }
-  o -= n_w1;
-  if (o < n_b1) {                                              // db1[j] = sum_b gh_avg + gh_mx
-    float acc = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < B; ++b) acc += A.s.gh_avg[b * h + o] + A.s.gh_mx[b * h + o];
-    A.gb1[o] = acc;
-    return;
-  }
-  o -= n_b1;
-  if (o < n_w2) {                                              // dW2[c,j] = sum_b g_z[b,c] * (h_avg[b,j] + h_mx[b,j])
-    const int c = o / h, j = o - c * h;
-    float acc = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < B; ++b) acc += A.s.gz[static_cast<size_t>(b) * C + c] * (A.c.h_avg[b * h + j] + A.c.h_mx[b * h + j]);
-    A.gw2[o] = acc;
-    return;
-  }
-  o -= n_w2;
-  {                                                            // db2[c] = 2 * sum_b g_z[b,c]   (bias used twice)
-    float acc = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < B; ++b) acc += A.s.gz[static_cast<size_t>(b) * C + o];
-    A.gb2[o] = 2.f * acc;
-  }
+  bwd_apply_body<T, VEC, GMASK>(A, local, smem, red);
 }
 
 }  // namespace mgacbam

@@ -43,6 +43,28 @@ __device__ __forceinline__ void store_vec(T* __restrict__ p, const float (&in)[V
   for (int e = 0; e < VEC; ++e) r.v[e] = from_f32<T>(in[e]);
   *reinterpret_cast<Pack<T, VEC>*>(p) = r;
 }
+// write-once streams (y, gx): non-temporal, so they do not displace x / gy (re-read by later kernels) from L2 / Infinity Cache
+template <typename T, int VEC>
+__device__ __forceinline__ void store_vec_stream(T* __restrict__ p, const float (&in)[VEC], bool nt) {
+  Pack<T, VEC> r;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) r.v[e] = from_f32<T>(in[e]);
+  if (nt) {
+    if constexpr (sizeof(T) * VEC == 16) {
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(*reinterpret_cast<v4f*>(&r), reinterpret_cast<v4f*>(p));
+    } else if constexpr (sizeof(T) * VEC == 8) {
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      __builtin_nontemporal_store(*reinterpret_cast<v2f*>(&r), reinterpret_cast<v2f*>(p));
+    } else if constexpr (sizeof(T) * VEC == 4) {
+      __builtin_nontemporal_store(*reinterpret_cast<float*>(&r), reinterpret_cast<float*>(p));
+    } else {
+      __builtin_nontemporal_store(*reinterpret_cast<unsigned short*>(&r), reinterpret_cast<unsigned short*>(p));
+    }
+  } else {
+    *reinterpret_cast<Pack<T, VEC>*>(p) = r;
+  }
+}
 template <int VEC>
 __device__ __forceinline__ void load_ivec(const int* __restrict__ p, int (&out)[VEC]) {
   Pack<int, VEC> r = *reinterpret_cast<const Pack<int, VEC>*>(p);

@@ -1,10 +1,14 @@
 // Forward kernels of the mask-guided CBAM block (reference mga_yolo/nn/modules/masked_cbam.py:87-171).
 //
-//   k_pool      x (1 read)            -> avg, mx (+ arg-max), S/use/den, sigma(mask) plane     [HBM-bound]
-//   k_mlp_fwd   avg, mx               -> h_avg, h_mx, ca                                        [tiny]
-//   k_chan      x (1 read), ca        -> planes[max_c, mean_c], cidx                            [HBM-bound]
-//   k_conv_fwd  planes                -> sa                                                     [tiny]
-//   k_apply     x (1 read), ca, sa    -> y (1 write)                                            [HBM-bound]
+//   k_pool   x (1 read)         -> avg, mx (+ arg-max), S/use/den, sigma(mask) plane                     [HBM-bound]
+//   k_chan   x (1 read)         -> prologue: shared MLP -> ca ; body: planes[max_c, mean_c], cidx         [HBM-bound]
+//   k_apply  x (1 read), planes -> prologue: k x k conv of the tile -> sa ; body: y (1 write)             [HBM-bound]
+//
+// Three launches, each covering P3+P4+P5.  The two tiny steps of the block (the MLP: <= 74k MAC per sample; the
+// conv: 147 MAC per pixel on 3 planes) run as PROLOGUES of the streaming kernels instead of launches of their own:
+// a dependent tiny launch costs >= 5 us on MI355X (2.5 us boundary + a first load that always misses, because the
+// producer's lines sit in another XCD's L2) whatever its arithmetic, while a prologue costs one such miss,
+// overlapped with the workgroup's first feature loads.
 //
 // No kernel materialises cam_out / sam_out / the expanded mask (the reference makes ~15 full-size
 // temporaries).  Thread layout everywhere: 256 threads = TY rows x TX lanes, TX lanes run along H*W
@@ -131,26 +135,24 @@ __global__ __launch_bounds__(kBlock) void k_pool(const Group<FwdArgs> G) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_mlp_fwd: shared MLP on both descriptors, channel gate                     masked_cbam.py:54-58, 128-129
-//   one workgroup per sample; <= 74k MAC per sample -- far too small for MFMA
+// shared MLP + channel gate for ONE sample, all channels, result in LDS           masked_cbam.py:54-58, 128-129
+//   s_in: 2*C floats scratch, s_h: 2*hidden, s_ca: C (output).  `publish` => also store ca, h_avg, h_mx of this
+//   sample to ctx (done by one workgroup per sample; backward and k_apply read them).
+//   (Holding W1/W2 slices in registers to issue all loads before the first barrier was tried: it cost ~40 VGPRs,
+//   dropped the streaming loop from 7 to 3 waves/SIMD and made k_chan 40 % slower -- profiles/r01 notes.)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_mlp_fwd(const Group<FwdArgs> G) {
-  extern __shared__ float sm[];
-  int local;
-  const int lvl = find_level(G, blockIdx.x, local);
-  const FwdArgs& A = G.lv[lvl];
+__device__ __forceinline__ void mlp_gate_to_lds(const FwdArgs& A, const int b, const bool publish,
+                                                float* s_in, float* s_h, float* s_ca) {
   const Geo& g = A.g;
-  const int b = local, tid = threadIdx.x, C = g.C, h = g.hidden;
-  float* s_avg = sm;
-  float* s_mx = sm + C;
-  float* s_ha = sm + 2 * C;
-  float* s_hm = s_ha + h;
+  const int tid = threadIdx.x, C = g.C, h = g.hidden;
+  const int wave = tid >> 6, lane = tid & 63;
+  float* s_avg = s_in;
+  float* s_mx = s_in + C;
   for (int c = tid; c < C; c += kBlock) {
     s_avg[c] = A.c.avg[static_cast<size_t>(b) * C + c];
     s_mx[c] = A.c.mx[static_cast<size_t>(b) * C + c];
   }
   __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63;
   for (int j = wave; j < h; j += kBlock / kWave) {
     const float* w = A.p.w1 + static_cast<size_t>(j) * C;
     float da = 0.f, dm = 0.f;
@@ -160,29 +162,37 @@ __global__ __launch_bounds__(kBlock) void k_mlp_fwd(const Group<FwdArgs> G) {
     if (lane == 0) {
       const float bj = A.p.b1[j];
       const float ha = fmaxf(da + bj, 0.f), hm = fmaxf(dm + bj, 0.f);
-      s_ha[j] = ha; s_hm[j] = hm;
-      A.c.h_avg[static_cast<size_t>(b) * h + j] = ha;
-      A.c.h_mx[static_cast<size_t>(b) * h + j] = hm;
+      s_h[j] = ha; s_h[h + j] = hm;
+      if (publish) {
+        A.c.h_avg[static_cast<size_t>(b) * h + j] = ha;
+        A.c.h_mx[static_cast<size_t>(b) * h + j] = hm;
+      }
     }
   }
   __syncthreads();
   for (int c = tid; c < C; c += kBlock) {
     const float* w = A.p.w2 + static_cast<size_t>(c) * h;
     float za = 0.f, zm = 0.f;
-    for (int j = 0; j < h; ++j) { const float wv = w[j]; za += wv * s_ha[j]; zm += wv * s_hm[j]; }
+    for (int j = 0; j < h; ++j) { const float wv = w[j]; za += wv * s_h[j]; zm += wv * s_h[h + j]; }
     const float bc = A.p.b2[c];
-    const float z = (za + bc) + (zm + bc);                   // masked_cbam.py:128 (bias enters twice)
-    A.c.ca[static_cast<size_t>(b) * C + c] = sigmoidf_(z);   // masked_cbam.py:129
+    const float z = (za + bc) + (zm + bc);
+    const float ca = sigmoidf_(z);
+    s_ca[c] = ca;
+    if (publish) A.c.ca[static_cast<size_t>(b) * C + c] = ca;
   }
+  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_chan: u = x * ca ; per pixel max_c u (+ first arg-max channel) and mean_c u        masked_cbam.py:130,135-136
-//   workgroup = (sample b, tile of TX vectors along H*W); row ty handles channels ty, ty+TY, ...;
-//   the TY partial (max, idx, sum) triples are combined through LDS.
+//   workgroup = (sample b, tile of TX vectors along H*W); row ty handles channels ty, ty+TY, ...; the TY partial
+//   (max, idx, sum) triples are combined through LDS.  Prologue: the sample's MLP (above); the first UN feature
+//   vectors of every lane are requested BEFORE it so the two latencies overlap.
+//   LDS: [2C scratch][2h][C ca][3*256*VEC combine]
 // ---------------------------------------------------------------------------------------------
 template <typename T, int VEC>
-__device__ __forceinline__ void chan_body(const FwdArgs& A, const int bid, float* sm) {
+__device__ __forceinline__ void chan_body(const FwdArgs& A, const int bid, float* smem) {
+  constexpr int UN = 4;
   const Geo& g = A.g;
   const int tid = threadIdx.x;
   const int TX = A.t.chan_tx, lt = ilog2(TX);
@@ -194,22 +204,44 @@ __device__ __forceinline__ void chan_body(const FwdArgs& A, const int bid, float
   const bool active = i < nv;
   const int ii = active ? i : nv - 1;
   const T* xp = static_cast<const T*>(A.x) + static_cast<size_t>(b) * g.C * g.HW + static_cast<size_t>(ii) * VEC;
-  const float* cab = A.c.ca + static_cast<size_t>(b) * g.C;
+
+  float x0[UN][VEC];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) load_vec<T, VEC>(xp + static_cast<size_t>(min(ty + u * TY, g.C - 1)) * g.HW, x0[u]);
+
+  float* s_in = smem;
+  float* s_h = smem + 2 * g.C;
+  float* s_ca = s_h + 2 * g.hidden;
+  float* sm = s_ca + g.C;
+  mlp_gate_to_lds(A, b, tile == 0, s_in, s_h, s_ca);
 
   float vmax[VEC], vsum[VEC];
   int vidx[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { vmax[e] = -INFINITY; vsum[e] = 0.f; vidx[e] = ty; }
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const int c = ty + u * TY;
+    if (c < g.C) {
+      const float cac = s_ca[c];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float uu = x0[u][e] * cac;                     // masked_cbam.py:130
+        vsum[e] += uu;
+        if (uu > vmax[e]) { vmax[e] = uu; vidx[e] = c; }
+      }
+    }
+  }
 #pragma unroll 4
-  for (int c = ty; c < g.C; c += TY) {
+  for (int c = ty + UN * TY; c < g.C; c += TY) {
     float xv[VEC];
     load_vec<T, VEC>(xp + static_cast<size_t>(c) * g.HW, xv);
-    const float cac = cab[c];
+    const float cac = s_ca[c];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const float u = xv[e] * cac;                           // masked_cbam.py:130
-      vsum[e] += u;
-      if (u > vmax[e]) { vmax[e] = u; vidx[e] = c; }
+      const float uu = xv[e] * cac;
+      vsum[e] += uu;
+      if (uu > vmax[e]) { vmax[e] = uu; vidx[e] = c; }
     }
   }
   float* smax = sm;
@@ -241,25 +273,52 @@ __device__ __forceinline__ void chan_body(const FwdArgs& A, const int bid, float
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void k_chan(const Group<FwdArgs> G) {
-  __shared__ float sm[kBlock * VEC * 3];
+  extern __shared__ __align__(16) float smem[];
   int local;
   const int l = find_level(G, blockIdx.x, local);
-  chan_body<T, VEC>(G.lv[l], local, sm);
+  chan_body<T, VEC>(G.lv[l], local, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
-// conv tiles (shared by k_conv_fwd and the backward conv kernels)
-//   a tile is TH rows x TW = 4*TWQ columns of one sample; NP planes of (TH+k-1) x (TW+k-1) floats (tile + halo,
-//   zero padded outside the image) are staged in LDS.  Loads are issued 8 at a time per thread before any LDS
-//   store so the global-load latency is paid once per batch, not once per element.
+// LDS staging of image planes with zero padding.  Loads are issued U at a time per thread before any LDS store,
+// so a tile costs one or two global-load latencies, not one per element.
+//   generic form: `total` elements, element idx -> (plane p, row yy, col xx) of a PH x PW window whose top-left
+//   image coordinate is (ya, xa); src(p) -> pointer to plane p of this sample (H*W floats)
 // ---------------------------------------------------------------------------------------------
+template <int U, typename SrcFn>
+__device__ __forceinline__ void stage_window(float* tile, int NP, int PH, int PW, int ya, int xa, const Geo& g, SrcFn src) {
+  const int total = NP * PH * PW;
+  const unsigned mpw = 0xFFFFFFFFu / static_cast<unsigned>(PW) + 1u;    // idx / PW == umulhi(idx, mpw) for idx < 2^16
+  const unsigned mph = 0xFFFFFFFFu / static_cast<unsigned>(PH) + 1u;
+  for (int base = 0; base < total; base += kBlock * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * kBlock + threadIdx.x;
+      const unsigned r = __umulhi(static_cast<unsigned>(idx), mpw);        // row over all planes
+      const int xx = idx - static_cast<int>(r) * PW;
+      const unsigned p = __umulhi(r, mph);
+      const int yy = static_cast<int>(r) - static_cast<int>(p) * PH;
+      const int gy_ = ya + yy, gx_ = xa + xx;
+      v[u] = 0.f;
+      if (idx < total && gy_ >= 0 && gy_ < g.H && gx_ >= 0 && gx_ < g.W) v[u] = src(static_cast<int>(p))[gy_ * g.W + gx_];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * kBlock + threadIdx.x;
+      if (idx < total) tile[idx] = v[u];
+    }
+  }
+}
+
+// 2-D conv tiles used by the backward conv kernel: TH rows x TW = 4*TWQ columns of one sample
 struct ConvTile {
   int b, y0, x0, TW, TH, PW, PH, pad, k;
 };
-__device__ __forceinline__ ConvTile conv_tile(const Geo& g, const Tune& t, int k, int bid) {
+__device__ __forceinline__ ConvTile conv_tile(const Geo& g, const Tune& t, int k, int bid, int th) {
   ConvTile c;
   c.k = k; c.pad = k / 2;
-  c.TW = t.conv_twq * 4; c.TH = t.conv_th;
+  c.TW = t.conv_twq * 4; c.TH = th;
   c.PW = c.TW + k - 1; c.PH = c.TH + k - 1;
   const int tiles_x = (g.W + c.TW - 1) / c.TW, tiles_y = (g.H + c.TH - 1) / c.TH;
   const int txi = bid % tiles_x; bid /= tiles_x;
@@ -268,155 +327,117 @@ __device__ __forceinline__ ConvTile conv_tile(const Geo& g, const Tune& t, int k
   c.y0 = tyi * c.TH; c.x0 = txi * c.TW;
   return c;
 }
-// src(p) -> pointer to plane p of this sample (H*W floats)
-template <int NP, typename SrcFn>
-__device__ __forceinline__ void stage_tiles(float* tile, const ConvTile& c, const Geo& g, SrcFn src) {
-  const int total = NP * c.PH * c.PW;
-  const unsigned mpw = 0xFFFFFFFFu / static_cast<unsigned>(c.PW) + 1u;    // idx / PW == umulhi(idx, mpw) for idx < 2^16
-  const unsigned mph = 0xFFFFFFFFu / static_cast<unsigned>(c.PH) + 1u;
-  for (int base = 0; base < total; base += kBlock * 8) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * kBlock + threadIdx.x;
-      const unsigned r = __umulhi(static_cast<unsigned>(idx), mpw);        // row over all planes
-      const int xx = idx - static_cast<int>(r) * c.PW;
-      const unsigned p = __umulhi(r, mph);
-      const int yy = static_cast<int>(r) - static_cast<int>(p) * c.PH;
-      const int gy_ = c.y0 + yy - c.pad, gx_ = c.x0 + xx - c.pad;
-      v[u] = 0.f;
-      if (idx < total && gy_ >= 0 && gy_ < g.H && gx_ >= 0 && gx_ < g.W) v[u] = src(static_cast<int>(p))[gy_ * g.W + gx_];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * kBlock + threadIdx.x;
-      if (idx < total) tile[idx] = v[u];
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
-// k_conv_fwd: sa = sigmoid(conv_kxk([max_c u, mean_c u, sigma(mask)]))         masked_cbam.py:146-147
-//   each thread produces 4 adjacent pixels so one LDS row segment of 4+k-1 floats feeds k taps x 4 outputs;
-//   weights sit in LDS (broadcast reads).  K > 0: compile-time kernel size; K == 0: any odd k <= 15.
+// k_apply: y = x + alpha * (x*ca*sa - x)                                       masked_cbam.py:130,146-148,166-171
+//   workgroup = (sample b, tile of TX vectors = TP contiguous pixels), rows take channel slices (k_chan's layout).
+//   Prologue: sa for the tile's TP pixels = sigmoid(conv_kxk([max_c u, mean_c u, sigma(mask)])): the image rows the
+//   tile touches (+ k/2 halo rows, full width + halo columns, zero padded) of the 3 planes are staged in LDS, one
+//   pixel per thread accumulates its 3*k*k taps, sa goes to LDS (for the body) and to ctx (for backward).
+//   LDS: [3*k*k weights][3 * nrows * (W+k-1) planes][TP sa]
 // ---------------------------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(kBlock) void k_conv_fwd(const Group<FwdArgs> G) {
-  extern __shared__ float smem[];
-  int local;
-  const int lvl = find_level(G, blockIdx.x, local);
-  const FwdArgs& A = G.lv[lvl];
-  const Geo& g = A.g;
-  const int k = K ? K : g.k;
-  const ConvTile c = conv_tile(g, A.t, k, local);
-  const int tid = threadIdx.x;
-  float* wts = smem;                                   // 3*k*k (rounded up to a multiple of 4 floats)
-  float* tile = smem + ((3 * k * k + 3) & ~3);
-  for (int i = tid; i < 3 * k * k; i += kBlock) wts[i] = A.p.wsa[i];
-  const float* pl = A.c.planes + static_cast<size_t>(c.b) * 3 * g.HW;
-  stage_tiles<3>(tile, c, g, [&](int p) { return pl + static_cast<size_t>(p) * g.HW; });
-  __syncthreads();
-  const int TWQ = A.t.conv_twq;
-  const int py = tid / TWQ, q = tid - py * TWQ;
-  if (py >= c.TH) return;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  constexpr int KK = K ? K : 1;
-  if (K) {
-#pragma unroll 1
-    for (int p = 0; p < 3; ++p) {
-#pragma unroll
-      for (int i = 0; i < KK; ++i) {
-        const float* row = tile + (p * c.PH + py + i) * c.PW + q * 4;
-        const float* wr = wts + (p * KK + i) * KK;
-        float r[4 + KK - 1];
-#pragma unroll
-        for (int t = 0; t < 4 + KK - 1; ++t) r[t] = row[t];
-#pragma unroll
-        for (int j = 0; j < KK; ++j) {
-          const float wv = wr[j];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] += wv * r[e + j];
-        }
-      }
-    }
-  } else {
-    for (int p = 0; p < 3; ++p)
-      for (int i = 0; i < k; ++i) {
-        const float* row = tile + (p * c.PH + py + i) * c.PW + q * 4;
-        const float* wr = wts + (p * k + i) * k;
-        for (int j = 0; j < k; ++j) {
-          const float wv = wr[j];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] += wv * row[e + j];
-        }
-      }
-  }
-  const int yg = c.y0 + py;
-  if (yg < g.H) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int xg = c.x0 + q * 4 + e;
-      if (xg < g.W) A.c.sa[static_cast<size_t>(c.b) * g.HW + yg * g.W + xg] = sigmoidf_(acc[e]);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_apply: y = x + alpha * (x*ca*sa - x)                                       masked_cbam.py:130,148,166-171
-//   same workgroup shape as k_pool: sa is loaded once per position and reused for CPT channels.
-// ---------------------------------------------------------------------------------------------
-template <typename T, int VEC, int CPT>
-__device__ __forceinline__ void apply_body(const FwdArgs& A, const int bid) {
+template <typename T, int VEC, int K>
+__device__ __forceinline__ void apply_body(const FwdArgs& A, const int bid, float* smem) {
+  constexpr int UN = 4;
   const Geo& g = A.g;
   const int tid = threadIdx.x;
-  const int TX = A.t.apply_tx, lt = ilog2(TX);
+  const int TX = A.t.chan_tx, lt = ilog2(TX);
   const int tx = tid & (TX - 1), ty = tid >> lt, TY = kBlock >> lt;
-  const int CPB = TY * CPT;
-  const int ncg = (g.C + CPB - 1) / CPB;
-  const int b = bid / ncg, cg = bid - b * ncg;
-  const int c0 = cg * CPB + ty * CPT;
   const int nv = g.HW / VEC;
-  const float a = softplusf_(*A.p.beta);                     // masked_cbam.py:150-152
+  const int ntile = (nv + TX - 1) / TX;
+  const int b = bid / ntile, tile = bid - b * ntile;
+  const int i = tile * TX + tx;
+  const bool active = i < nv;
+  const int ii = active ? i : nv - 1;
+  const size_t base = static_cast<size_t>(b) * g.C * g.HW + static_cast<size_t>(ii) * VEC;
+  const T* xp = static_cast<const T*>(A.x) + base;
+  T* yp = static_cast<T*>(A.y) + base;
+  const float* cab = A.c.ca + static_cast<size_t>(b) * g.C;
 
-  const T* xr[CPT];
-  T* yr[CPT];
-  float cac[CPT];
-  bool live[CPT];
+  float x0[UN][VEC];
 #pragma unroll
-  for (int j = 0; j < CPT; ++j) {
-    live[j] = (c0 + j) < g.C;
-    const int c = min(c0 + j, g.C - 1);
-    const size_t o = static_cast<size_t>(b) * g.C + c;
-    xr[j] = static_cast<const T*>(A.x) + o * g.HW;
-    yr[j] = static_cast<T*>(A.y) + o * g.HW;
-    cac[j] = A.c.ca[o];
-  }
-  const float* sab = A.c.sa + static_cast<size_t>(b) * g.HW;
-  for (int i = tx; i < nv; i += TX) {
-    float sav[VEC];
-    load_vec<float, VEC>(sab + static_cast<size_t>(i) * VEC, sav);
-    float xv[CPT][VEC];
+  for (int u = 0; u < UN; ++u) load_vec<T, VEC>(xp + static_cast<size_t>(min(ty + u * TY, g.C - 1)) * g.HW, x0[u]);
+
+  // ---- prologue: spatial gate of this tile -------------------------------------------------------------------
+  const int k = K ? K : g.k, pad = k / 2;
+  const int TP = TX * VEC;
+  const int p0 = tile * TP;                                     // first pixel of the tile
+  const int p1 = min(p0 + TP, g.HW) - 1;                        // last pixel
+  const int r0 = p0 / g.W, r1 = p1 / g.W;
+  const int PW = g.W + k - 1, PH = (r1 - r0 + 1) + k - 1;
+  float* wts = smem;
+  float* planes = smem + ((3 * k * k + 3) & ~3);
+  float* s_sa = planes + 3 * A.t.apply_rows * PW;               // apply_rows >= PH (host-computed bound)
+  for (int t = tid; t < 3 * k * k; t += kBlock) wts[t] = A.p.wsa[t];
+  const float* pl = A.c.planes + static_cast<size_t>(b) * 3 * g.HW;
+  stage_window<12>(planes, 3, PH, PW, r0 - pad, -pad, g, [&](int p) { return pl + static_cast<size_t>(p) * g.HW; });
+  __syncthreads();
+  if (tid < TP && p0 + tid < g.HW) {
+    const int p = p0 + tid;
+    const int py = p / g.W, px = p - py * g.W;
+    const float* origin = planes + (py - r0) * PW + px;         // tap (i,j) of plane q: origin[q*PH*PW + i*PW + j]
+    float acc = 0.f;
+    if (K) {
+      constexpr int KK = K ? K : 1;
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) load_vec<T, VEC>(xr[j] + static_cast<size_t>(i) * VEC, xv[j]);
+      for (int q = 0; q < 3; ++q) {
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-      float yv[VEC];
+        for (int ti = 0; ti < KK; ++ti) {
+          const float* row = origin + q * PH * PW + ti * PW;
+          const float* wr = wts + (q * KK + ti) * KK;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const float u = xv[j][e] * cac[j];                   // masked_cbam.py:130
-        const float v = u * sav[e];                          // masked_cbam.py:148
-        yv[e] = xv[j][e] + a * (v - xv[j][e]);               // masked_cbam.py:171
+          for (int tj = 0; tj < KK; ++tj) acc += wr[tj] * row[tj];
+        }
       }
-      if (live[j]) store_vec<T, VEC>(yr[j] + static_cast<size_t>(i) * VEC, yv);
+    } else {
+      for (int q = 0; q < 3; ++q)
+        for (int ti = 0; ti < k; ++ti) {
+          const float* row = origin + q * PH * PW + ti * PW;
+          const float* wr = wts + (q * k + ti) * k;
+          for (int tj = 0; tj < k; ++tj) acc += wr[tj] * row[tj];
+        }
     }
+    const float sa = sigmoidf_(acc);                            // masked_cbam.py:147
+    s_sa[tid] = sa;
+    A.c.sa[static_cast<size_t>(b) * g.HW + p] = sa;
+  }
+  __syncthreads();
+  float sav[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) sav[e] = active ? s_sa[tx * VEC + e] : 0.f;
+  const float a = softplusf_(*A.p.beta);                        // masked_cbam.py:150-152
+
+  // ---- body ------------------------------------------------------------------------------------------------------
+  auto emit = [&](const float (&xv)[VEC], int c) {
+    const float cac = cab[c];
+    float yv[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float u = xv[e] * cac;                              // masked_cbam.py:130
+      const float v = u * sav[e];                               // masked_cbam.py:148
+      yv[e] = xv[e] + a * (v - xv[e]);                          // masked_cbam.py:171
+    }
+    if (active) store_vec_stream<T, VEC>(yp + static_cast<size_t>(c) * g.HW, yv, A.t.nt_stores);
+  };
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const int c = ty + u * TY;
+    if (c < g.C) emit(x0[u], c);
+  }
+#pragma unroll 4
+  for (int c = ty + UN * TY; c < g.C; c += TY) {
+    float xv[VEC];
+    load_vec<T, VEC>(xp + static_cast<size_t>(c) * g.HW, xv);
+    emit(xv, c);
   }
 }
 
-template <typename T, int VEC, int CPT>
+template <typename T, int VEC, int K>
 __global__ __launch_bounds__(kBlock) void k_apply(const Group<FwdArgs> G) {
+  extern __shared__ __align__(16) float smem[];
   int local;
   const int l = find_level(G, blockIdx.x, local);
-  apply_body<T, VEC, CPT>(G.lv[l], local);
+  apply_body<T, VEC, K>(G.lv[l], local, smem);
 }
 
 // ---------------------------------------------------------------------------------------------

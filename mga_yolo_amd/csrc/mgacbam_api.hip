@@ -95,7 +95,7 @@ static bool is_pow2_in(int v, int lo, int hi) { return v >= lo && v <= hi && (v 
 
 static int vec_of(int H, int W) { return ((static_cast<long long>(H) * W) % 4 == 0) ? 4 : 1; }
 
-static Tune choose_tune(int B, int C, int H, int W) {
+static Tune choose_tune(int B, int C, int H, int W, int k) {
   const int HW = H * W, VEC = vec_of(H, W), nv = HW / VEC;
   Tune t;
   // rows of TX lanes sweep H*W: aim for >= 4 sweeps per lane, then shrink channels/row until the grid fills the chip
@@ -117,8 +117,15 @@ static Tune choose_tune(int B, int C, int H, int W) {
   int th = 256 / t.conv_twq;
   if (th > H) th = H;
   if (th > 64) th = 64;
+  const int cap = 24 * 256 / (4 * (tw + k - 1)) - (k - 1);  // 4 staged planes (tile + halo) in <= 24 loads per thread
+  if (th > cap) th = cap;
   if (th < 1) th = 1;
   t.conv_th = th;
+  int wth = 3500 / (4 * (tw + k - 1)) - (k - 1);                // dWsa tiles: 4 staged planes (tile + halo) <= ~14 KB of LDS
+  if (wth > H) wth = H;
+  if (wth > 64) wth = 64;
+  if (wth < 1) wth = 1;
+  t.wsa_th = wth;
   // experiment hooks (tests / tuning sweeps); ignored when not a legal value
   int v;
   if (is_pow2_in(v = env_int("MGACBAM_POOL_TX", 0), 1, 256)) t.pool_tx = v;
@@ -126,6 +133,11 @@ static Tune choose_tune(int B, int C, int H, int W) {
   if (is_pow2_in(v = env_int("MGACBAM_APPLY_TX", 0), 1, 256)) t.apply_tx = v;
   if ((v = env_int("MGACBAM_APPLY_CPT", 0)) == 1 || v == 2 || v == 4) t.apply_cpt = v;
   if (is_pow2_in(v = env_int("MGACBAM_CHAN_TX", 0), 1, 64)) t.chan_tx = v;
+  // k_apply stages every image row its TX*VEC-pixel tile touches, plus the k-1 halo rows
+  int rows = (t.chan_tx * VEC - 1) / W + 2;
+  if (rows > H) rows = H;
+  t.apply_rows = rows + k - 1;
+  t.nt_stores = env_int("MGACBAM_NT", 1) ? 1 : 0;
   return t;
 }
 
@@ -133,16 +145,20 @@ static int conv_tiles(const Tune& t, int H, int W) {
   const int TW = t.conv_twq * 4;
   return ((W + TW - 1) / TW) * ((H + t.conv_th - 1) / t.conv_th);
 }
+static int wsa_tiles(const Tune& t, int H, int W) {
+  const int TW = t.conv_twq * 4;
+  return ((W + TW - 1) / TW) * ((H + t.wsa_th - 1) / t.wsa_th);
+}
 static int chan_tiles(const Tune& t, int H, int W) {
   const int nv = H * W / vec_of(H, W);
   return (nv + t.chan_tx - 1) / t.chan_tx;
 }
 
-struct ScratchLayout { size_t A_part, Q_part, gpre, gplanes, gwsa_part, gz, gbq, gh_avg, gh_mx, chan4, Kb, total; };
+struct ScratchLayout { size_t A_part, Q_part, gpre, gplanes, gwsa_part, gz, gbq, gh_avg, gh_mx, chan4, Kb, pgh, total; };
 static ScratchLayout scratch_layout(int B, int C, int H, int W, int hidden, int k) {
-  const Tune t = choose_tune(B, C, H, W);
+  const Tune t = choose_tune(B, C, H, W, k);
   const size_t HW = static_cast<size_t>(H) * W, BC = static_cast<size_t>(B) * C;
-  const size_t nt = chan_tiles(t, H, W), nconv = static_cast<size_t>(B) * conv_tiles(t, H, W);
+  const size_t nt = chan_tiles(t, H, W), nconv = static_cast<size_t>(B) * wsa_tiles(t, H, W);
   ScratchLayout L;
   size_t o = 0;
   auto take = [&](size_t n_elems) { size_t at = o; o = align16(o + n_elems * 4); return at; };
@@ -151,7 +167,9 @@ static ScratchLayout scratch_layout(int B, int C, int H, int W, int hidden, int 
   L.gwsa_part = take(nconv * 3 * k * k);
   L.gz = take(BC); L.gbq = take(BC);
   L.gh_avg = take(static_cast<size_t>(B) * hidden); L.gh_mx = take(static_cast<size_t>(B) * hidden);
-  L.chan4 = take(BC * 4); L.Kb = take(B);
+  L.chan4 = take(4); L.Kb = take(B);
+  const size_t ty = kBlock / t.pool_tx;                               // channel groups per sample, worst case (1 channel per row)
+  L.pgh = take(static_cast<size_t>(B) * ((C + ty - 1) / ty) * hidden);
   L.total = o;
   return L;
 }
@@ -233,9 +251,19 @@ static int sweep_blocks(const Args& a, int tx, int cpt) {
   const int cpb = (kBlock / tx) * cpt;
   return a.g.B * ((a.g.C + cpb - 1) / cpb);
 }
-static size_t conv_smem(const Tune& t, int k, int planes) {
-  return (((3 * k * k + 3) & ~3) + static_cast<size_t>(planes) * (t.conv_th + k - 1) * (t.conv_twq * 4 + k - 1)) * sizeof(float);
+static size_t convT_smem(const Tune& t, int k) {
+  return (((3 * k * k + 3) & ~3) + static_cast<size_t>(t.conv_th + k - 1) * (t.conv_twq * 4 + k - 1)) * sizeof(float);
 }
+static size_t wsa_smem(const Tune& t, int k) {
+  return (4 * static_cast<size_t>(t.wsa_th + k - 1) * (t.conv_twq * 4 + k - 1) + static_cast<size_t>(3 * k * t.wsa_th) * k) * sizeof(float);
+}
+static size_t params_smem(const Geo& g) { return (3 * static_cast<size_t>(g.B) + 2 * kBlock) * sizeof(float); }
+static int params_blocks(const Geo& g) { return g.hidden + (g.C + kBlock - 1) / kBlock + (3 * g.k * g.k + 3) / 4 + 1; }
+static size_t chan_smem(const Geo& g, int vec) { return (3 * static_cast<size_t>(g.C) + 2 * g.hidden + 3 * kBlock * vec) * sizeof(float); }
+static size_t apply_smem(const Geo& g, const Tune& t, int vec) {
+  return (((3 * g.k * g.k + 3) & ~3) + 3 * static_cast<size_t>(t.apply_rows) * (g.W + g.k - 1) + t.chan_tx * vec) * sizeof(float);
+}
+static size_t bwd_apply_smem(const Geo& g, int vec) { return (4 * static_cast<size_t>(g.C) + 2 * g.hidden + kBlock * vec) * sizeof(float); }
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -253,7 +281,7 @@ static int forward_args(const mgacbam_fwd_level_t& L, FwdArgs& A, Sig& sig) {
   A.c = ctx_ptrs(L.ctx, L.B, L.C, L.H, L.W, L.p.hidden);
   A.p = make_params(L.p);
   A.g = make_geo(L.B, L.C, L.H, L.W, L.p);
-  A.t = choose_tune(L.B, L.C, L.H, L.W);
+  A.t = choose_tune(L.B, L.C, L.H, L.W, L.p.k);
   sig = Sig{L.dtype, VEC, L.mask != nullptr, L.p.k, 0};
   return 0;
 }
@@ -261,8 +289,8 @@ static int forward_args(const mgacbam_fwd_level_t& L, FwdArgs& A, Sig& sig) {
 static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStream_t st) {
   Group<FwdArgs> G;
   G.n = n;
-  const int pool_cpt = group_cpt(lv, n, false), apply_cpt = group_cpt(lv, n, true);
-  for (int l = 0; l < n; ++l) { lv[l].t.pool_cpt = pool_cpt; lv[l].t.apply_cpt = apply_cpt; G.lv[l] = lv[l]; }
+  const int pool_cpt = group_cpt(lv, n, false);
+  for (int l = 0; l < n; ++l) { lv[l].t.pool_cpt = pool_cpt; G.lv[l] = lv[l]; }
   auto fill = [&](auto blocks_of) { int tot = 0; for (int l = 0; l < n; ++l) { G.start[l] = tot; tot += blocks_of(lv[l]); } G.start[n] = tot; return tot; };
 
   if (stages & MGACBAM_FWD_POOL) {  // 1. pooling
@@ -274,39 +302,28 @@ static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStre
 #undef CALL_POOL2
     if (int e = launch_status("k_pool")) return e;
   }
-  if (stages & MGACBAM_FWD_MLP) {  // 2. shared MLP + channel gate
+  if (stages & MGACBAM_FWD_CHAN) {  // 2. shared MLP + channel gate (prologue), channel max / mean planes
     size_t smem = 0;
-    for (int l = 0; l < n; ++l) smem = std::max(smem, (2 * static_cast<size_t>(lv[l].g.C) + 2 * lv[l].g.hidden) * sizeof(float));
-    const int grid = fill([&](const FwdArgs& a) { return a.g.B; });
-    LAUNCH(k_mlp_fwd, grid, smem, st, G);
-    if (int e = launch_status("k_mlp_fwd")) return e;
-  }
-  if (stages & MGACBAM_FWD_CHAN) {  // 3. channel max / mean planes
+    for (int l = 0; l < n; ++l) smem = std::max(smem, chan_smem(lv[l].g, sig.vec));
     const int grid = fill([&](const FwdArgs& a) { return a.g.B * chan_tiles(a.t, a.g.H, a.g.W); });
-#define CALL_CHAN(Tt, Vv) LAUNCH((k_chan<Tt, Vv>), grid, 0, st, G)
+#define CALL_CHAN(Tt, Vv) LAUNCH((k_chan<Tt, Vv>), grid, smem, st, G)
     DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_CHAN);
 #undef CALL_CHAN
     if (int e = launch_status("k_chan")) return e;
   }
-  if (stages & MGACBAM_FWD_CONV) {  // 4. k x k conv + sigmoid
+  if (stages & MGACBAM_FWD_APPLY) {  // 3. k x k conv + spatial gate (prologue), both gates + alpha residual
     size_t smem = 0;
-    for (int l = 0; l < n; ++l) smem = std::max(smem, conv_smem(lv[l].t, sig.k, 3));
-    const int grid = fill([&](const FwdArgs& a) { return a.g.B * conv_tiles(a.t, a.g.H, a.g.W); });
-    switch (sig.k) {
-      case 3: LAUNCH(k_conv_fwd<3>, grid, smem, st, G); break;
-      case 5: LAUNCH(k_conv_fwd<5>, grid, smem, st, G); break;
-      case 7: LAUNCH(k_conv_fwd<7>, grid, smem, st, G); break;
-      default: LAUNCH(k_conv_fwd<0>, grid, smem, st, G); break;
+    for (int l = 0; l < n; ++l) smem = std::max(smem, apply_smem(lv[l].g, lv[l].t, sig.vec));
+    const int grid = fill([&](const FwdArgs& a) { return a.g.B * chan_tiles(a.t, a.g.H, a.g.W); });
+#define CALL_APPLY(Tt, Vv)                                                    \
+    switch (sig.k) {                                                          \
+      case 3: LAUNCH((k_apply<Tt, Vv, 3>), grid, smem, st, G); break;         \
+      case 5: LAUNCH((k_apply<Tt, Vv, 5>), grid, smem, st, G); break;         \
+      case 7: LAUNCH((k_apply<Tt, Vv, 7>), grid, smem, st, G); break;         \
+      default: LAUNCH((k_apply<Tt, Vv, 0>), grid, smem, st, G); break;        \
     }
-    if (int e = launch_status("k_conv_fwd")) return e;
-  }
-  if (stages & MGACBAM_FWD_APPLY) {  // 5. apply both gates + alpha residual
-    const int grid = fill([&](const FwdArgs& a) { return sweep_blocks(a, a.t.apply_tx, apply_cpt); });
-#define CALL_APPLY2(CPTV) LAUNCH((k_apply<TT, VV, CPTV>), grid, 0, st, G)
-#define CALL_APPLY(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; DISPATCH_CPT(apply_cpt, CALL_APPLY2); }
     DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_APPLY);
 #undef CALL_APPLY
-#undef CALL_APPLY2
     if (int e = launch_status("k_apply")) return e;
   }
   return 0;
@@ -363,7 +380,7 @@ static int backward_args(const mgacbam_bwd_level_t& L, BwdArgs& A, Sig& sig) {
   A.c = ctx_ptrs(const_cast<void*>(L.ctx), L.B, L.C, L.H, L.W, L.p.hidden);
   A.p = make_params(L.p);
   A.g = make_geo(L.B, L.C, L.H, L.W, L.p);
-  A.t = choose_tune(L.B, L.C, L.H, L.W);
+  A.t = choose_tune(L.B, L.C, L.H, L.W, L.p.k);
   const ScratchLayout SL = scratch_layout(L.B, L.C, L.H, L.W, L.p.hidden, L.p.k);
   char* sp = static_cast<char*>(L.scratch);
   A.s.A_part = reinterpret_cast<float*>(sp + SL.A_part); A.s.Q_part = reinterpret_cast<float*>(sp + SL.Q_part);
@@ -372,9 +389,12 @@ static int backward_args(const mgacbam_bwd_level_t& L, BwdArgs& A, Sig& sig) {
   A.s.gz = reinterpret_cast<float*>(sp + SL.gz); A.s.gbq = reinterpret_cast<float*>(sp + SL.gbq);
   A.s.gh_avg = reinterpret_cast<float*>(sp + SL.gh_avg); A.s.gh_mx = reinterpret_cast<float*>(sp + SL.gh_mx);
   A.s.chan4 = reinterpret_cast<float*>(sp + SL.chan4); A.s.Kb = reinterpret_cast<float*>(sp + SL.Kb);
+  A.s.pgh = reinterpret_cast<float*>(sp + SL.pgh);
   A.nt = chan_tiles(A.t, A.g.H, A.g.W);
   A.nconv = A.g.B * conv_tiles(A.t, A.g.H, A.g.W);
-  A.r2_blocks = 0;
+  A.nwsa = A.g.B * wsa_tiles(A.t, A.g.H, A.g.W);
+  A.npg = params_blocks(A.g);
+  A.ncg = 0;
   sig = Sig{L.dtype, VEC, L.mask != nullptr, L.p.k, L.gmask != nullptr};
   return 0;
 }
@@ -383,7 +403,12 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
   Group<BwdArgs> G;
   G.n = n;
   const int cpt = group_cpt(lv, n, false);
-  for (int l = 0; l < n; ++l) { lv[l].t.pool_cpt = cpt; lv[l].r2_blocks = sweep_blocks(lv[l], lv[l].t.pool_tx, cpt); G.lv[l] = lv[l]; }
+  for (int l = 0; l < n; ++l) {
+    lv[l].t.pool_cpt = cpt;
+    const int cpb = (kBlock / lv[l].t.pool_tx) * cpt;
+    lv[l].ncg = (lv[l].g.C + cpb - 1) / cpb;
+    G.lv[l] = lv[l];
+  }
   auto fill = [&](auto blocks_of) { int tot = 0; for (int l = 0; l < n; ++l) { G.start[l] = tot; tot += blocks_of(lv[l]); } G.start[n] = tot; return tot; };
 
   if (stages & MGACBAM_BWD_REDUCE1) {  // 1. per-(b,c) and per-pixel reductions of gy*x
@@ -395,7 +420,7 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
   }
   if (stages & MGACBAM_BWD_CONVT) {  // 2. transposed conv
     size_t smem = 0;
-    for (int l = 0; l < n; ++l) smem = std::max(smem, conv_smem(lv[l].t, sig.k, 1));
+    for (int l = 0; l < n; ++l) smem = std::max(smem, convT_smem(lv[l].t, sig.k));
     const int grid = fill([&](const BwdArgs& a) { return a.nconv; });
     switch (sig.k) {
       case 3: LAUNCH(k_bwd_convT<3>, grid, smem, st, G); break;
@@ -405,37 +430,54 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
     }
     if (int e = launch_status("k_bwd_convT")) return e;
   }
-  if (stages & MGACBAM_BWD_REDUCE2) {  // 3. rest of g_ca (needs g_planes), g_z; dWsa partials ride along as role workgroups
-    size_t smem = 64 * sizeof(float);
-    for (int l = 0; l < n; ++l) smem = std::max(smem, conv_smem(lv[l].t, sig.k, 4));
-    const int grid = fill([&](const BwdArgs& a) { return a.nconv + a.r2_blocks; });
-#define CALL_R22(CPTV) LAUNCH((k_bwd_reduce2<TT, VV, CPTV>), grid, smem, st, G)
+  const bool fuse = (stages & MGACBAM_BWD_FUSE) != 0;
+  const bool fuse_wsa = fuse && (stages & MGACBAM_BWD_REDUCE2) && (stages & MGACBAM_BWD_WSA) && sig.k == 7;
+  const bool fuse_pg = fuse && (stages & MGACBAM_BWD_APPLY) && (stages & MGACBAM_BWD_PARAMGRAD);
+  if (stages & MGACBAM_BWD_REDUCE2) {  // 3. rest of g_ca (needs g_planes), g_z [+ dWsa partials as role workgroups]
+    size_t smem = 0;
+    for (int l = 0; l < n; ++l) {
+      smem = std::max(smem, (64 + static_cast<size_t>(kBlock / lv[l].t.pool_tx) * lv[l].g.hidden) * sizeof(float));
+      if (fuse_wsa) smem = std::max(smem, wsa_smem(lv[l].t, sig.k));
+    }
+    const int grid = fill([&](const BwdArgs& a) { return (fuse_wsa ? a.nwsa : 0) + sweep_blocks(a, a.t.pool_tx, cpt); });
+#define CALL_R22(CPTV) if (fuse_wsa) LAUNCH((k_bwd_reduce2<TT, VV, CPTV, true>), grid, smem, st, G); else LAUNCH((k_bwd_reduce2<TT, VV, CPTV, false>), grid, smem, st, G)
 #define CALL_R2(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; DISPATCH_CPT(cpt, CALL_R22); }
     DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_R2);
 #undef CALL_R2
 #undef CALL_R22
     if (int e = launch_status("k_bwd_reduce2")) return e;
   }
-  if (stages & MGACBAM_BWD_MLP) {  // 4. shared-MLP backward
+  if ((stages & MGACBAM_BWD_WSA) && !fuse_wsa) {  // 4. dWsa tile partials (depends on stage 1 only)
     size_t smem = 0;
-    for (int l = 0; l < n; ++l) smem = std::max(smem, (static_cast<size_t>(lv[l].g.C) + 2 * lv[l].g.hidden) * sizeof(float));
-    const int grid = fill([&](const BwdArgs& a) { return a.g.B; });
-    LAUNCH(k_bwd_mlp, grid, smem, st, G);
-    if (int e = launch_status("k_bwd_mlp")) return e;
+    for (int l = 0; l < n; ++l) smem = std::max(smem, wsa_smem(lv[l].t, sig.k));
+    const int grid = fill([&](const BwdArgs& a) { return a.nwsa; });
+    switch (sig.k) {
+      case 3: LAUNCH(k_bwd_wsa<3>, grid, smem, st, G); break;
+      case 5: LAUNCH(k_bwd_wsa<5>, grid, smem, st, G); break;
+      case 7: LAUNCH(k_bwd_wsa<7>, grid, smem, st, G); break;
+      default: LAUNCH(k_bwd_wsa<0>, grid, smem, st, G); break;
+    }
+    if (int e = launch_status("k_bwd_wsa")) return e;
   }
-  if (stages & MGACBAM_BWD_FINALIZE) {  // 5. parameter gradients (do not depend on stage 6)
-    const int grid = fill([&](const BwdArgs& a) {
-      const int total = 2 * a.g.C * a.g.hidden + a.g.C + a.g.hidden;
-      return (total + kBlock - 1) / kBlock + (3 * a.g.k * a.g.k + 3) / 4 + 1;
-    });
-    LAUNCH(k_bwd_finalize, grid, 0, st, G);
-    if (int e = launch_status("k_bwd_finalize")) return e;
+  if ((stages & MGACBAM_BWD_PARAMGRAD) && !fuse_pg) {  // 5. every parameter gradient
+    size_t smem = 0;
+    for (int l = 0; l < n; ++l) smem = std::max(smem, params_smem(lv[l].g));
+    const int grid = fill([&](const BwdArgs& a) { return a.npg; });
+    LAUNCH(k_bwd_params, grid, smem, st, G);
+    if (int e = launch_status("k_bwd_params")) return e;
   }
-  if (stages & MGACBAM_BWD_APPLY) {  // 6. gx (+ gmask)
-    const int grid = fill([&](const BwdArgs& a) { return a.g.B * a.nt; });
-#define CALL_AP(Tt, Vv) if (sig.gmask) LAUNCH((k_bwd_apply<Tt, Vv, true>), grid, 0, st, G); else LAUNCH((k_bwd_apply<Tt, Vv, false>), grid, 0, st, G)
+  if (stages & MGACBAM_BWD_APPLY) {  // 6. gx (+ gmask) [+ parameter gradients as role workgroups]
+    size_t smem = 0;
+    for (int l = 0; l < n; ++l) {
+      smem = std::max(smem, bwd_apply_smem(lv[l].g, sig.vec));
+      if (fuse_pg) smem = std::max(smem, params_smem(lv[l].g));
+    }
+    const int grid = fill([&](const BwdArgs& a) { return (fuse_pg ? a.npg : 0) + a.g.B * a.nt; });
+#define CALL_AP2(GM) if (fuse_pg) LAUNCH((k_bwd_apply<TT, VV, GM, true>), grid, smem, st, G); else LAUNCH((k_bwd_apply<TT, VV, GM, false>), grid, smem, st, G)
+#define CALL_AP(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; if (sig.gmask) { CALL_AP2(true); } else { CALL_AP2(false); } }
     DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_AP);
 #undef CALL_AP
+#undef CALL_AP2
     if (int e = launch_status("k_bwd_apply")) return e;
   }
   return 0;

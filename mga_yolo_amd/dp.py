@@ -5,9 +5,11 @@ The reference trains with DistributedDataParallel (U/engine/trainer.py:366-367):
 (``batch // world_size``, trainer.py:379), one bucketed all-reduce(mean) of parameter gradients per step.  The block has no
 cross-sample reduction, so its data path needs no collective; only its parameter gradients are exchanged:
 47 KB (YOLOv8n) to 302 KB (l) per step.  At that size an all-reduce over xGMI is latency-bound, not bandwidth-bound, so
-the one thing that matters is to START it early: ``PyramidPlan.backward_params()`` completes every parameter gradient
-before the large input-gradient kernel runs, ``GradExchange.start()`` then launches the all-reduce of ONE flat bucket on a
-side stream while ``backward_inputs()`` streams gx on the compute stream, and ``finish()`` joins the two.
+what matters is to hide its latency behind work that does not need the averaged gradients: ``GradExchange.start()``
+launches the all-reduce of ONE flat bucket on a side stream, ``finish()`` joins it into the compute stream.  Callers put
+independent work between the two -- bench.py overlaps it with the next step's parameter-free pooling kernel; a caller
+that wants the overlap inside the step uses ``PyramidPlan.backward_params()`` (every parameter gradient complete),
+``start()``, ``backward_inputs()`` (the big input-gradient kernel), ``finish()``.
 """
 from __future__ import annotations
 
@@ -51,7 +53,7 @@ class GradExchange:
             self._work = dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
-        if self.world == 1:
+        if self.world == 1 or self._work is None:
             return
         if self.on_gpu:
             with torch.cuda.stream(self.side):

@@ -4,9 +4,9 @@ are launch-latency bound (a full pass over the 52 MB P3 feature is ~10 us of HBM
 step are recorded once and replayed, instead of being issued from Python every step.
 
 A ``PyramidPlan`` owns, per level: x, mask, y, gy, gx, gmask, ctx, scratch; and ONE flat fp32 bucket holding the parameter
-gradients of all levels (what data-parallel training all-reduces, see ``dp.py``).  ``forward`` / ``backward_params`` /
-``backward_inputs`` each make one library call on the current stream; ``backward_params`` finishes everything the
-parameter gradients depend on, so their all-reduce can overlap ``backward_inputs`` (gx, gmask).
+gradients of all levels (what data-parallel training all-reduces, see ``dp.py``).  ``forward`` / ``backward`` each make ONE
+library call on the current stream (7 kernel launches per step in total).  ``backward_params`` + ``backward_inputs`` is
+the split form for callers that want the parameter gradients early (see ``dp.py``).
 """
 from __future__ import annotations
 
@@ -72,9 +72,12 @@ class PyramidPlan:
         _lib.check(self.lib.mgacbam_backward_stages(self._bwd, self.n, stages, self._stream()), "mgacbam_backward_stages")
 
     def backward_params(self):
+        """Every stage the parameter gradients depend on, as separate launches: they are complete when this returns to the
+        stream, so a data-parallel caller can start their all-reduce and overlap it with ``backward_inputs``."""
         self.backward(_lib.BWD_PARAMS)
 
     def backward_inputs(self):
+        """k_bwd_apply: gx and gmask."""
         self.backward(_lib.BWD_INPUTS)
 
     # ------------------------------------------------------------------ hipGraph capture
