@@ -146,7 +146,7 @@ def _host_forward(x: torch.Tensor, mask: Optional[torch.Tensor], params, cfg: Bl
     flat = x.flatten(2)                                                        # (B,C,N)
     gap = flat.mean(dim=2)
     if mask is None:
-        avg, mx = gap, flat.amax(dim=2)
+        avg, mx = gap, flat.max(dim=2)[0]                                      # index path: the first maximum gets the gradient
         plane = x.new_zeros(B, 1, H, W)
     else:
         m = mask.unsqueeze(1) if mask.dim() == 3 else mask
@@ -159,12 +159,12 @@ def _host_forward(x: torch.Tensor, mask: Optional[torch.Tensor], params, cfg: Bl
         mavg = (flat * sf).sum(dim=2) / total.clamp_min(cfg.eps)
         avg = mavg * use + gap * (1.0 - use)
         low = torch.finfo(x.dtype).min
-        mmax = flat.masked_fill(~(sf > 0.5), low).amax(dim=2)
+        mmax = flat.masked_fill(~(sf > 0.5), low).max(dim=2)[0]
         mx = torch.where(torch.isclose(mmax, torch.full_like(mmax, low)), gap, mmax)
         plane = s
     gate = lambda d: F.linear(F.relu(F.linear(d, w1.to(d.dtype), b1.to(d.dtype))), w2.to(d.dtype), b2.to(d.dtype))
     ca = torch.sigmoid(gate(avg) + gate(mx)).view(B, Cc, 1, 1)
     u = x * ca
-    planes = torch.cat([u.amax(dim=1, keepdim=True), u.mean(dim=1, keepdim=True), plane], dim=1)
+    planes = torch.cat([u.max(dim=1, keepdim=True)[0], u.mean(dim=1, keepdim=True), plane], dim=1)
     sa = torch.sigmoid(F.conv2d(planes, wsa.to(x.dtype), padding=cfg.k // 2))
     return x + F.softplus(beta).to(x.dtype) * (u * sa - x)

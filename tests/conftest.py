@@ -92,3 +92,15 @@ def rel_err(a, b):
 @pytest.fixture(scope="session")
 def checksums():
     return load_checksums()
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """libmgacbam.so, (re)built in-tree if sources are newer (hipcc cross-compiles gfx950 without a GPU)."""
+    from mga_yolo_amd import build as B
+    try:
+        return B.build()
+    except RuntimeError as e:
+        if os.path.exists(B.LIB):
+            return B.LIB
+        pytest.skip(f"cannot build libmgacbam.so here: {e}")

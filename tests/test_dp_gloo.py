@@ -1,0 +1,83 @@
+"""Data-parallel path on CPU: world_size 2, gloo.  Each rank runs the block on its minibatch shard (the oracle stands in
+for the kernels here -- tests may use it), the flat parameter-gradient bucket is averaged by GradExchange, and the result
+must equal what a single process gets on the whole batch (DDP semantics: mean over replicas)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, synth
+
+
+def _worker(rank, world, port, B, C, H, W, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mga_yolo_amd.dp import GradExchange, shard_batch
+    from oracle import maskcbam_oracle as O
+    x, mask, gy = synth(B, C, H, W, seed=42)
+    p = O.Params.default_init(C)
+    sl = shard_batch(B, world, rank)
+    xs, ms, gs = x[sl], mask[sl], gy[sl]
+    y, ctx = O.forward(xs, ms, p)
+    g = O.backward(gs, xs, ms, p, O.Config(), ctx)
+    names = ("gw1", "gb1", "gw2", "gb2", "gwsa", "gbeta")
+    bucket = torch.cat([g[n].reshape(-1) for n in names])      # one flat bucket, as PyramidPlan.grad_bucket
+    ex = GradExchange(bucket)
+    ex.start()
+    overlapped = float(y.sum())                                 # independent work between start() and finish()
+    ex.finish()
+    ex.finish()                                                 # idempotent when nothing is pending
+    q.put((rank, bucket.clone(), g["gx"].clone(), sl.start, sl.stop, overlapped))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_exchange_matches_single_process():
+    from oracle import maskcbam_oracle as O
+    B, C, H, W, world = 4, 32, 10, 10, 2
+    ctx_mp = mp.get_context("spawn")
+    q = ctx_mp.Queue()
+    port = 29500 + (os.getpid() % 400)
+    procs = [ctx_mp.Process(target=_worker, args=(r, world, port, B, C, H, W, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    x, mask, gy = synth(B, C, H, W, seed=42)
+    p = O.Params.default_init(C)
+    y, c = O.forward(x, mask, p)
+    g = O.backward(gy, x, mask, p, O.Config(), c)
+    want = torch.cat([g[n].reshape(-1) for n in ("gw1", "gb1", "gw2", "gb2", "gwsa", "gbeta")]) / world
+    for rank, bucket, gx, lo, hi, _ in got:
+        assert (bucket - want).abs().max() <= 1e-5 * want.abs().max(), rank      # same averaged bucket on every rank
+        assert (gx - g["gx"][lo:hi]).abs().max() <= 1e-6 * g["gx"].abs().max()    # no collective in the data path
+    assert torch.equal(got[0][1], got[1][1])
+
+
+def test_shard_batch_is_an_equal_contiguous_partition():
+    from mga_yolo_amd.dp import shard_batch
+    seen = []
+    for r in range(8):
+        s = shard_batch(256, 8, r)
+        assert s.stop - s.start == 32
+        seen += list(range(s.start, s.stop))
+    assert seen == list(range(256))
+    with pytest.raises(ValueError):
+        shard_batch(30, 8, 0)
+
+
+def test_exchange_is_a_no_op_without_a_process_group():
+    from mga_yolo_amd.dp import GradExchange
+    b = torch.arange(6, dtype=torch.float32)
+    ex = GradExchange(b)
+    ex.start(); ex.finish()
+    assert ex.world == 1 and torch.equal(b, torch.arange(6, dtype=torch.float32))

@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference module interface (mga_yolo_amd/module.py, install.py): contract tests on CPU."""
+import copy
+import os
+import pickle
+import sys
+import types
+
+import pytest
+import torch
+
+from conftest import golden_case_names, load_golden, rel_err, synth
+
+
+def _module_for(d):
+    from mga_yolo_amd import MaskCBAM
+    C = d["x"].shape[1]
+    m = MaskCBAM(C, r=d["meta"]["r"], spatial_k=d["meta"]["k"], use_sigmoid_mask=d["meta"]["use_sigmoid_mask"])
+    m.load_state_dict(d["params"])          # reference state_dict loads as-is: same keys and shapes
+    return m
+
+
+def test_state_dict_contract_and_default_init_match_reference():
+    """Keys / shapes / creation order of the reference: the same seed gives the same initial values."""
+    from mga_yolo_amd import MaskCBAM
+    d = load_golden("base")
+    torch.manual_seed(0)
+    m = MaskCBAM(64)
+    sd = m.state_dict()
+    assert list(sd) == ["beta", "cam_mlp.0.weight", "cam_mlp.0.bias", "cam_mlp.2.weight", "cam_mlp.2.bias", "sam_conv.weight"]
+    for k, v in sd.items():
+        assert torch.equal(v, d["params"][k]), k
+    assert sd["beta"].shape == () and sd["beta"].dtype == torch.float32
+    assert abs(float(m.alpha) - 0.6931472) < 1e-6          # softplus(0) = ln 2
+    assert "channels=64" in m.extra_repr() and "alpha=0.6931" in m.extra_repr()
+    assert MaskCBAM(32, spatial_k=6).k == 7                # even kernel sizes are bumped to the next odd
+    assert MaskCBAM(8).hidden == 1 and MaskCBAM(192).hidden == 12
+    names = [n for n, _ in m.named_parameters()]
+    assert [n for n in names if "bias" in n] == ["cam_mlp.0.bias", "cam_mlp.2.bias"]   # optimizer grouping by name
+
+
+@pytest.mark.parametrize("name", golden_case_names())
+def test_host_path_matches_reference_golden(name):
+    """CPU tensors (build-time stride probe, device='cpu' runs) take the plain-PyTorch statement: same results as the reference."""
+    d = load_golden(name)
+    m = _module_for(d)
+    x = d["x"].clone().requires_grad_(True)
+    mk = None if d["mask"] is None else d["mask"].clone().requires_grad_(True)
+    y = m(x if mk is None else [x, mk])
+    y.backward(d["gy"])
+    assert type(y) is torch.Tensor and y.shape == x.shape
+    assert rel_err(y, d["out"]["y"]) < 1e-5
+    assert rel_err(x.grad, d["out"]["gx"]) < 1e-4
+    if mk is not None:
+        assert rel_err(mk.grad, d["out"]["gmask"]) < 1e-4
+    got = {"gw1": m.cam_mlp[0].weight.grad, "gb1": m.cam_mlp[0].bias.grad, "gw2": m.cam_mlp[2].weight.grad,
+           "gb2": m.cam_mlp[2].bias.grad, "gwsa": m.sam_conv.weight.grad, "gbeta": m.beta.grad}
+    for k, v in got.items():
+        assert rel_err(v, d["out"][k]) < 1e-4, k
+
+
+def test_input_contract():
+    from mga_yolo_amd import MaskCBAM
+    m = MaskCBAM(16)
+    x, mask, _ = synth(2, 16, 8, 8)
+    y_list, y_tuple = m([x, mask]), m((x, mask))
+    assert torch.equal(y_list, y_tuple)
+    assert torch.equal(m([x, mask[:, 0]]), y_list)          # (B,H,W) mask
+    assert m(x).shape == x.shape                            # plain tensor = no mask
+    with pytest.raises(AssertionError):
+        m([x, mask, mask])
+    with pytest.raises(AssertionError):
+        m(x[0])
+    with pytest.raises(RuntimeError):                       # mismatched mask size is an error, as in the reference
+        m([x, torch.zeros(2, 1, 4, 4)])
+    zeros = m.eval()([torch.zeros(1, 16, 32, 32), torch.zeros(1, 1, 32, 32)])   # the parse_model stride probe
+    assert torch.equal(zeros, torch.zeros_like(zeros))
+
+
+def test_module_is_deepcopy_and_pickle_safe():
+    """EMA deep-copies the model and checkpoints pickle state: no ctypes handle may live on the instance."""
+    from mga_yolo_amd import MaskCBAM
+    m = MaskCBAM(32)
+    m2 = copy.deepcopy(m)
+    m3 = pickle.loads(pickle.dumps(m))
+    x, mask, _ = synth(1, 32, 6, 6)
+    assert torch.equal(m([x, mask]), m2([x, mask])) and torch.equal(m([x, mask]), m3([x, mask]))
+    m.i, m.f, m.type, m.np = 23, [15, 22], "MaskCBAM", 728   # parse_model attaches these (U/nn/tasks.py:1763-1766)
+    assert m.f == [15, 22]
+
+
+def test_forward_hooks_see_a_plain_tensor():
+    from mga_yolo_amd import MaskCBAM
+    m = MaskCBAM(16)
+    seen = []
+    h = m.register_forward_hook(lambda mod, inp, out: seen.append(out.detach().clone()))
+    x, mask, _ = synth(1, 16, 4, 4)
+    y = m([x, mask])
+    h.remove()
+    assert len(seen) == 1 and torch.equal(seen[0], y)
+
+
+def test_install_rebinds_the_reference_lookups():
+    """parse_model resolves 'MaskCBAM' through ultralytics.nn.tasks globals and tests identity against the same name."""
+    from mga_yolo_amd import MaskCBAM, install
+    fake = {}
+    for name in ("ultralytics", "ultralytics.nn", "ultralytics.nn.tasks", "mga_yolo", "mga_yolo.nn", "mga_yolo.nn.modules",
+                 "mga_yolo.nn.modules.masked_cbam"):
+        fake[name] = types.ModuleType(name)
+    class Old:  # noqa: E306
+        pass
+    fake["ultralytics.nn.tasks"].MaskCBAM = Old
+    fake["ultralytics.nn"].MaskCBAM = Old
+    fake["mga_yolo.nn.modules.masked_cbam"].MaskCBAM = Old
+    saved = {k: sys.modules.get(k) for k in fake}
+    sys.modules.update(fake)
+    try:
+        patched = install(strict=True)
+        assert "ultralytics.nn.tasks" in patched and "mga_yolo.nn.modules.masked_cbam" in patched
+        tasks = sys.modules["ultralytics.nn.tasks"]
+        assert tasks.MaskCBAM is MaskCBAM and vars(tasks)["MaskCBAM"] is MaskCBAM      # globals()[m] and `m is MaskCBAM`
+        built = vars(tasks)["MaskCBAM"](64)                                            # parse_model: MaskCBAM(c_in)
+        assert isinstance(built, sys.modules["mga_yolo.nn.modules.masked_cbam"].MaskCBAM)   # trainer's alpha logger
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_prob_mask_gater_semantics():
+    from mga_yolo_amd import ProbMaskGater
+    p = torch.tensor([[[-0.5, 0.2], [0.7, 1.8]]])            # (1,2,2): 3-D input, values outside [0,1] get clamped
+    g = ProbMaskGater(mode="gumbel")
+    g.eval()
+    out = g(p)
+    assert out.shape == (1, 1, 2, 2) and torch.equal(out.flatten(), torch.tensor([0.0, 0.2, 0.7, 1.0]))
+    assert torch.equal(ProbMaskGater(mode="deterministic").train()(p), out)
+    assert torch.equal(ProbMaskGater(mode="deterministic", p_min=0.3)(p).flatten(), torch.tensor([0.3, 0.3, 0.7, 1.0]))
+    with pytest.raises(ValueError):
+        ProbMaskGater(tau=0.0)
+    big = torch.rand(4, 1, 16, 16)
+    g1, g2 = ProbMaskGater(mode="gumbel", seed=5).train(), ProbMaskGater(mode="gumbel", seed=5).train()
+    a, b = g1(big), g2(big)
+    assert torch.equal(a, b) and 0 < float(a.min()) and float(a.max()) < 1 and not torch.equal(a, g1(big))
+    hs = ProbMaskGater(mode="hard_st", seed=1).train()
+    q = big.clone().requires_grad_(True)
+    o = hs(q)
+    assert set(o.detach().unique().tolist()) <= {0.0, 1.0}
+    o.sum().backward()
+    assert q.grad.abs().sum() > 0                            # straight-through gradient
+    bd = ProbMaskGater(mode="bernoulli_detach", seed=2).train()(q)
+    assert set(bd.unique().tolist()) <= {0.0, 1.0} and not bd.requires_grad
+
+
+def test_prob_mode_environment_switch(monkeypatch):
+    from mga_yolo_amd import MaskCBAM, ProbMaskGater
+    monkeypatch.delenv("MGA_PROB_MODE", raising=False)
+    assert not hasattr(MaskCBAM(16), "gater")
+    monkeypatch.setenv("MGA_PROB_MODE", "False")              # any non-empty string is truthy, as in the reference
+    monkeypatch.setenv("MGA_PROB_APPROACH", "deterministic")
+    m = MaskCBAM(16)
+    assert isinstance(m.gater, ProbMaskGater) and m.gater.mode == "deterministic"
+    x, mask, _ = synth(1, 16, 4, 4)
+    monkeypatch.delenv("MGA_PROB_MODE")
+    ref = m([x, mask.clamp(0, 1)])                            # deterministic gate = clamp to [0,1] before the block
+    monkeypatch.setenv("MGA_PROB_MODE", "1")
+    assert torch.equal(m([x, mask]), ref)
+    monkeypatch.setenv("MGA_PROB_APPROACH", "nonsense")
+    with pytest.raises(ValueError):
+        MaskCBAM(16)
