@@ -32,7 +32,8 @@ __device__ __forceinline__ void bwd_reduce1_body(const BwdArgs& A, const int bid
   const int tx = tid & (TX - 1), ty = tid >> lt, TY = kBlock >> lt;
   const int nv = g.HW / VEC;
   const int ntile = A.nt;
-  const int b = bid / ntile, tile = bid - b * ntile;
+  int b, tile;
+  if (!xcd_sample_part(bid, g.B, ntile, b, tile)) return;
   const int i = tile * TX + tx;
   const bool active = i < nv;
   const int ii = active ? i : nv - 1;
@@ -263,7 +264,8 @@ __device__ __forceinline__ void bwd_reduce2_body(const BwdArgs& A, const int bid
   const int tx = tid & (TX - 1), ty = tid >> lt, TY = kBlock >> lt;
   const int CPB = TY * CPT;
   const int ncg = (g.C + CPB - 1) / CPB;
-  const int b = bid / ncg, cg = bid - b * ncg;
+  int b, cg;
+  if (!xcd_sample_part(bid, g.B, ncg, b, cg)) return;
   const int c0 = cg * CPB + ty * CPT;
   const int nv = g.HW / VEC;
   const float invC = 1.f / static_cast<float>(g.C);
@@ -358,8 +360,9 @@ __global__ __launch_bounds__(kBlock) void k_bwd_reduce2(const Group<BwdArgs> G) 
   const int l = find_level(G, blockIdx.x, local);
   const BwdArgs& A = G.lv[l];
   if (ROLES) {
-    if (local < A.nwsa) { bwd_wsa_body<7>(A, local, smem); return; }
-    local -= A.nwsa;
+    const int npad = (A.nwsa + 7) & ~7;                         // keeps the streaming ids' id % 8 <-> sample alignment
+    if (local < npad) { if (local < A.nwsa) bwd_wsa_body<7>(A, local, smem); return; }
+    local -= npad;
   }
   bwd_reduce2_body<T, VEC, CPT>(A, local, smem);
 }
@@ -488,7 +491,8 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
   const int tx = tid & (TX - 1), ty = tid >> lt, TY = kBlock >> lt;
   const int nv = g.HW / VEC;
   const int ntile = (nv + TX - 1) / TX;
-  const int b = bid / ntile, tile = bid - b * ntile;
+  int b, tile;
+  if (!xcd_sample_part(bid, g.B, ntile, b, tile)) return;
   const int i = tile * TX + tx;
   const bool active = i < nv;
   const int ii = active ? i : nv - 1;
@@ -637,8 +641,9 @@ __global__ __launch_bounds__(kBlock) void k_bwd_apply(const Group<BwdArgs> G) {
   const int l = find_level(G, blockIdx.x, local);
   const BwdArgs& A = G.lv[l];
   if (ROLES) {
-    if (local < A.npg) { bwd_params_body(A, local, smem, red); return; }
-    local -= A.npg;
+    const int npad = (A.npg + 7) & ~7;
+    if (local < npad) { if (local < A.npg) bwd_params_body(A, local, smem, red); return; }
+    local -= npad;
   }
   bwd_apply_body<T, VEC, GMASK>(A, local, smem, red);
 }

@@ -34,7 +34,8 @@ __device__ __forceinline__ void pool_body(const FwdArgs& A, const int bid, float
   const int tx = tid & (TX - 1), ty = tid >> lt, TY = kBlock >> lt;
   const int CPB = TY * CPT;
   const int ncg = (g.C + CPB - 1) / CPB;
-  const int b = bid / ncg, cg = bid - b * ncg;
+  int b, cg;
+  if (!xcd_sample_part(bid, g.B, ncg, b, cg)) return;
   const int c0 = cg * CPB + ty * CPT;
   const int nv = g.HW / VEC;
 
@@ -199,7 +200,8 @@ __device__ __forceinline__ void chan_body(const FwdArgs& A, const int bid, float
   const int tx = tid & (TX - 1), ty = tid >> lt, TY = kBlock >> lt;
   const int nv = g.HW / VEC;
   const int ntile = (nv + TX - 1) / TX;
-  const int b = bid / ntile, tile = bid - b * ntile;
+  int b, tile;
+  if (!xcd_sample_part(bid, g.B, ntile, b, tile)) return;
   const int i = tile * TX + tx;
   const bool active = i < nv;
   const int ii = active ? i : nv - 1;
@@ -345,7 +347,8 @@ __device__ __forceinline__ void apply_body(const FwdArgs& A, const int bid, floa
   const int tx = tid & (TX - 1), ty = tid >> lt, TY = kBlock >> lt;
   const int nv = g.HW / VEC;
   const int ntile = (nv + TX - 1) / TX;
-  const int b = bid / ntile, tile = bid - b * ntile;
+  int b, tile;
+  if (!xcd_sample_part(bid, g.B, ntile, b, tile)) return;
   const int i = tile * TX + tx;
   const bool active = i < nv;
   const int ii = active ? i : nv - 1;

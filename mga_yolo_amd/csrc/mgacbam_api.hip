@@ -240,16 +240,19 @@ static int group_cpt(const Args* lv, int n, bool apply_kernel) {
     for (int l = 0; l < n; ++l) {
       const int tx = apply_kernel ? lv[l].t.apply_tx : lv[l].t.pool_tx;
       const int cpb = (kBlock / tx) * cpt;
-      blocks += static_cast<long long>(lv[l].g.B) * ((lv[l].g.C + cpb - 1) / cpb);
+      blocks += static_cast<long long>(lv[l].g.B) * ((lv[l].g.C + cpb - 1) / cpb);   // real workgroups (padding ids exit at once)
     }
     if (blocks >= 1536) return cpt;
   }
   return 1;
 }
+// grids are XCD-aligned (common.cuh: xcd_sample_part): ceil(B/8)*8 sample slots x parts
+static int xcd_grid(int B, int parts) { return ((B + 7) / 8) * 8 * parts; }
+static int pad8(int n) { return (n + 7) & ~7; }
 template <typename Args>
 static int sweep_blocks(const Args& a, int tx, int cpt) {
   const int cpb = (kBlock / tx) * cpt;
-  return a.g.B * ((a.g.C + cpb - 1) / cpb);
+  return xcd_grid(a.g.B, (a.g.C + cpb - 1) / cpb);
 }
 static size_t convT_smem(const Tune& t, int k) {
   return (((3 * k * k + 3) & ~3) + static_cast<size_t>(t.conv_th + k - 1) * (t.conv_twq * 4 + k - 1)) * sizeof(float);
@@ -305,7 +308,7 @@ static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStre
   if (stages & MGACBAM_FWD_CHAN) {  // 2. shared MLP + channel gate (prologue), channel max / mean planes
     size_t smem = 0;
     for (int l = 0; l < n; ++l) smem = std::max(smem, chan_smem(lv[l].g, sig.vec));
-    const int grid = fill([&](const FwdArgs& a) { return a.g.B * chan_tiles(a.t, a.g.H, a.g.W); });
+    const int grid = fill([&](const FwdArgs& a) { return xcd_grid(a.g.B, chan_tiles(a.t, a.g.H, a.g.W)); });
 #define CALL_CHAN(Tt, Vv) LAUNCH((k_chan<Tt, Vv>), grid, smem, st, G)
     DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_CHAN);
 #undef CALL_CHAN
@@ -314,7 +317,7 @@ static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStre
   if (stages & MGACBAM_FWD_APPLY) {  // 3. k x k conv + spatial gate (prologue), both gates + alpha residual
     size_t smem = 0;
     for (int l = 0; l < n; ++l) smem = std::max(smem, apply_smem(lv[l].g, lv[l].t, sig.vec));
-    const int grid = fill([&](const FwdArgs& a) { return a.g.B * chan_tiles(a.t, a.g.H, a.g.W); });
+    const int grid = fill([&](const FwdArgs& a) { return xcd_grid(a.g.B, chan_tiles(a.t, a.g.H, a.g.W)); });
 #define CALL_APPLY(Tt, Vv)                                                    \
     switch (sig.k) {                                                          \
       case 3: LAUNCH((k_apply<Tt, Vv, 3>), grid, smem, st, G); break;         \
@@ -412,7 +415,7 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
   auto fill = [&](auto blocks_of) { int tot = 0; for (int l = 0; l < n; ++l) { G.start[l] = tot; tot += blocks_of(lv[l]); } G.start[n] = tot; return tot; };
 
   if (stages & MGACBAM_BWD_REDUCE1) {  // 1. per-(b,c) and per-pixel reductions of gy*x
-    const int grid = fill([&](const BwdArgs& a) { return a.g.B * a.nt; });
+    const int grid = fill([&](const BwdArgs& a) { return xcd_grid(a.g.B, a.nt); });
 #define CALL_R1(Tt, Vv) LAUNCH((k_bwd_reduce1<Tt, Vv>), grid, 0, st, G)
     DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_R1);
 #undef CALL_R1
@@ -439,7 +442,7 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
       smem = std::max(smem, (64 + static_cast<size_t>(kBlock / lv[l].t.pool_tx) * lv[l].g.hidden) * sizeof(float));
       if (fuse_wsa) smem = std::max(smem, wsa_smem(lv[l].t, sig.k));
     }
-    const int grid = fill([&](const BwdArgs& a) { return (fuse_wsa ? a.nwsa : 0) + sweep_blocks(a, a.t.pool_tx, cpt); });
+    const int grid = fill([&](const BwdArgs& a) { return (fuse_wsa ? pad8(a.nwsa) : 0) + sweep_blocks(a, a.t.pool_tx, cpt); });
 #define CALL_R22(CPTV) if (fuse_wsa) LAUNCH((k_bwd_reduce2<TT, VV, CPTV, true>), grid, smem, st, G); else LAUNCH((k_bwd_reduce2<TT, VV, CPTV, false>), grid, smem, st, G)
 #define CALL_R2(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; DISPATCH_CPT(cpt, CALL_R22); }
     DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_R2);
@@ -472,7 +475,7 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
       smem = std::max(smem, bwd_apply_smem(lv[l].g, sig.vec));
       if (fuse_pg) smem = std::max(smem, params_smem(lv[l].g));
     }
-    const int grid = fill([&](const BwdArgs& a) { return (fuse_pg ? a.npg : 0) + a.g.B * a.nt; });
+    const int grid = fill([&](const BwdArgs& a) { return (fuse_pg ? pad8(a.npg) : 0) + xcd_grid(a.g.B, a.nt); });
 #define CALL_AP2(GM) if (fuse_pg) LAUNCH((k_bwd_apply<TT, VV, GM, true>), grid, smem, st, G); else LAUNCH((k_bwd_apply<TT, VV, GM, false>), grid, smem, st, G)
 #define CALL_AP(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; if (sig.gmask) { CALL_AP2(true); } else { CALL_AP2(false); } }
     DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_AP);
