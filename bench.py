@@ -35,6 +35,10 @@ WORKLOADS = {
     # name: (description, per-GPU batch, [(C, H, W) for P3, P4, P5])
     "cfg2": ("YOLOv8n+MGA-CBAM P3/P4/P5, 32x640x640 synthetic per GPU, fp32 (BASELINE.json configs[1])", 32,
              [(64, 80, 80), (128, 40, 40), (256, 20, 20)]),
+    # single-level diagnostics (not benchmark lines)
+    "p3": ("diagnostic: P3 only of cfg2", 32, [(64, 80, 80)]),
+    "p4": ("diagnostic: P4 only of cfg2", 32, [(128, 40, 40)]),
+    "p5": ("diagnostic: P5 only of cfg2", 32, [(256, 20, 20)]),
     "cfg1": ("YOLOv8n+MGA-CBAM P3/P4/P5, 2x640x640 (BASELINE.json configs[0] shapes)", 2,
              [(64, 80, 80), (128, 40, 40), (256, 20, 20)]),
     "cfg3": ("YOLOv8s+MGA-CBAM P3/P4/P5, 32x640x640 per GPU (BASELINE.json configs[2] shapes)", 32,

@@ -25,7 +25,7 @@ namespace mgacbam {
 // k_bwd_reduce1     (thread layout of k_chan: one H*W vector per lane, rows take channel slices; TX <= 64)
 // ---------------------------------------------------------------------------------------------
 template <typename T, int VEC>
-__device__ __forceinline__ void bwd_reduce1_body(const BwdArgs& A, const int bid, float* sm) {
+__device__ __forceinline__ void bwd_reduce1_body(const BwdArgs& A, const int bid, float* smem) {
   const Geo& g = A.g;
   const int tid = threadIdx.x;
   const int TX = A.t.chan_tx, lt = ilog2(TX);
@@ -40,8 +40,12 @@ __device__ __forceinline__ void bwd_reduce1_body(const BwdArgs& A, const int bid
   const size_t base = static_cast<size_t>(b) * g.C * g.HW + static_cast<size_t>(ii) * VEC;
   const T* xp = static_cast<const T*>(A.x) + base;
   const T* gp = static_cast<const T*>(A.gy) + base;
-  const float* cab = A.c.ca + static_cast<size_t>(b) * g.C;
   const float a = softplusf_(*A.p.beta);
+  // LDS: [C ca][2*C tile partials (A then Q)][256*VEC combine]
+  float* s_ca = smem;
+  float* s_aq = smem + g.C;
+  float* sm = s_aq + 2 * g.C;
+  for (int c = tid; c < g.C; c += kBlock) s_ca[c] = A.c.ca[static_cast<size_t>(b) * g.C + c];
 
   float sav[VEC];
   load_vec<float, VEC>(A.c.sa + static_cast<size_t>(b) * g.HW + static_cast<size_t>(ii) * VEC, sav);
@@ -49,13 +53,14 @@ __device__ __forceinline__ void bwd_reduce1_body(const BwdArgs& A, const int bid
   float accp[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) accp[e] = 0.f;
+  __syncthreads();
 
 #pragma unroll 4
   for (int c = ty; c < g.C; c += TY) {
     float xv[VEC], gv[VEC];
     load_vec<T, VEC>(xp + static_cast<size_t>(c) * g.HW, xv);
     load_vec<T, VEC>(gp + static_cast<size_t>(c) * g.HW, gv);
-    const float cac = cab[c];
+    const float cac = s_ca[c];
     float pa = 0.f, pq = 0.f;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -66,15 +71,14 @@ __device__ __forceinline__ void bwd_reduce1_body(const BwdArgs& A, const int bid
     }
     pa = wave_group_sum(pa, TX);
     pq = wave_group_sum(pq, TX);
-    if (tx == 0) {
-      const size_t o = (static_cast<size_t>(b) * g.C + c) * ntile + tile;
-      A.s.A_part[o] = pa;
-      A.s.Q_part[o] = pq;
-    }
+    if (tx == 0) { s_aq[c] = pa; s_aq[g.C + c] = pq; }
   }
 #pragma unroll
   for (int e = 0; e < VEC; ++e) sm[tid * VEC + e] = accp[e];
   __syncthreads();
+  // this tile's partials of A[b,c] and Q[b,c], written as two contiguous runs of C floats (layout (B, nt, 2, C))
+  float* part = A.s.A_part + (static_cast<size_t>(b) * ntile + tile) * 2 * g.C;
+  for (int c = tid; c < 2 * g.C; c += kBlock) part[c] = s_aq[c];
   if (ty == 0 && active) {
     for (int r = 1; r < TY; ++r) {
       const int o = (r * TX + tx) * VEC;
@@ -90,10 +94,10 @@ __device__ __forceinline__ void bwd_reduce1_body(const BwdArgs& A, const int bid
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void k_bwd_reduce1(const Group<BwdArgs> G) {
-  __shared__ float sm[kBlock * VEC];
+  extern __shared__ __align__(16) float smem[];
   int local;
   const int l = find_level(G, blockIdx.x, local);
-  bwd_reduce1_body<T, VEC>(G.lv[l], local, sm);
+  bwd_reduce1_body<T, VEC>(G.lv[l], local, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -306,9 +310,9 @@ __device__ __forceinline__ void bwd_reduce2_body(const BwdArgs& A, const int bid
   float sums[3 * CPT];
 #pragma unroll
   for (int j = 0; j < CPT; ++j) {
-    const size_t o = (static_cast<size_t>(b) * g.C + cj[j]) * A.nt;
+    const float* part = A.s.A_part + static_cast<size_t>(b) * A.nt * 2 * g.C + cj[j];
     float As = 0.f, Qs = 0.f;
-    for (int t = tx; t < A.nt; t += TX) { As += A.s.A_part[o + t]; Qs += A.s.Q_part[o + t]; }
+    for (int t = tx; t < A.nt; t += TX) { As += part[static_cast<size_t>(t) * 2 * g.C]; Qs += part[static_cast<size_t>(t) * 2 * g.C + g.C]; }
     sums[j] = acc[j]; sums[CPT + j] = As; sums[2 * CPT + j] = Qs;
   }
   row_sum<3 * CPT>(sums, TX, tid, red);
@@ -536,7 +540,8 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
 
   // ---- prologue: q[c] and K_b for this sample -------------------------------------------------------------------
   float4* s_q = reinterpret_cast<float4*>(smem);
-  float* s_gh = smem + 4 * g.C;
+  int* s_am = reinterpret_cast<int*>(smem + 4 * g.C);          // arg-max position of (b,c), -1 when the GAP fallback was used
+  float* s_gh = smem + 5 * g.C;
   float* sm = s_gh + 2 * g.hidden;
   const int h = g.hidden;
   const float live = (has_mask && A.c.S[b] >= g.eps) ? 1.f : 0.f;   // clamp_min passes grad only when not clamped
@@ -574,6 +579,7 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
     q.z = valid ? gm : 0.f;
     q.w = valid ? 0.f : gm / N;
     s_q[c] = q;
+    s_am[c] = valid ? amax[c] : -1;
     kpart += ga * A.c.mavg[o] * live;
   }
 
@@ -585,7 +591,7 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
   auto emit = [&](const float (&gv)[VEC], const float (&xv)[VEC], int c) {
     float ov[VEC];
     const float4 q = s_q[c];
-    const int am = amax[c] - ii * VEC;                        // offset of the arg-max inside this vector, if any
+    const int am = s_am[c] - ii * VEC;                        // offset of the arg-max inside this vector, if any
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       float r = gv[e] * ((1.f - a) + sav[e] * q.x);

@@ -371,7 +371,9 @@ __device__ __forceinline__ void apply_body(const FwdArgs& A, const int bid, floa
   float* wts = smem;
   float* planes = smem + ((3 * k * k + 3) & ~3);
   float* s_sa = planes + 3 * A.t.apply_rows * PW;               // apply_rows >= PH (host-computed bound)
+  float* s_ca = s_sa + TX * VEC;
   for (int t = tid; t < 3 * k * k; t += kBlock) wts[t] = A.p.wsa[t];
+  for (int c = tid; c < g.C; c += kBlock) s_ca[c] = cab[c];
   const float* pl = A.c.planes + static_cast<size_t>(b) * 3 * g.HW;
   stage_window<12>(planes, 3, PH, PW, r0 - pad, -pad, g, [&](int p) { return pl + static_cast<size_t>(p) * g.HW; });
   __syncthreads();
@@ -412,7 +414,7 @@ __device__ __forceinline__ void apply_body(const FwdArgs& A, const int bid, floa
 
   // ---- body ------------------------------------------------------------------------------------------------------
   auto emit = [&](const float (&xv)[VEC], int c) {
-    const float cac = cab[c];
+    const float cac = s_ca[c];
     float yv[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {

@@ -107,7 +107,8 @@ static Tune choose_tune(int B, int C, int H, int W, int k) {
   t.apply_tx = tx; t.apply_cpt = cpt;
   // one H*W vector per lane, TY channel slices: TX <= 64 so row reductions are pure wave shuffles
   int ctx = pow2_ceil(nv) < 64 ? pow2_ceil(nv) : 64;
-  while (ctx > 16 && static_cast<long long>(B) * ((nv + ctx - 1) / ctx) < 768) ctx /= 2;
+  const int min_tx = env_int("MGACBAM_CHAN_MINTX", 16);
+  while (ctx > min_tx && static_cast<long long>(B) * ((nv + ctx - 1) / ctx) < 768) ctx /= 2;
   while (ctx < 64 && (256 / ctx) * 4 > C) ctx *= 2;       // keep >= 4 channels per row
   t.chan_tx = ctx;
   // conv tiles: full rows when W <= 128, otherwise equal column strips; 4 px per thread
@@ -162,7 +163,7 @@ static ScratchLayout scratch_layout(int B, int C, int H, int W, int hidden, int 
   ScratchLayout L;
   size_t o = 0;
   auto take = [&](size_t n_elems) { size_t at = o; o = align16(o + n_elems * 4); return at; };
-  L.A_part = take(BC * nt); L.Q_part = take(BC * nt);
+  L.A_part = take(2 * BC * nt); L.Q_part = take(4);       // tile partials of A and Q live together: (B, nt, 2, C)
   L.gpre = take(B * HW); L.gplanes = take(static_cast<size_t>(B) * 3 * HW);
   L.gwsa_part = take(nconv * 3 * k * k);
   L.gz = take(BC); L.gbq = take(BC);
@@ -264,9 +265,10 @@ static size_t params_smem(const Geo& g) { return (3 * static_cast<size_t>(g.B) +
 static int params_blocks(const Geo& g) { return g.hidden + (g.C + kBlock - 1) / kBlock + (3 * g.k * g.k + 3) / 4 + 1; }
 static size_t chan_smem(const Geo& g, int vec) { return (3 * static_cast<size_t>(g.C) + 2 * g.hidden + 3 * kBlock * vec) * sizeof(float); }
 static size_t apply_smem(const Geo& g, const Tune& t, int vec) {
-  return (((3 * g.k * g.k + 3) & ~3) + 3 * static_cast<size_t>(t.apply_rows) * (g.W + g.k - 1) + t.chan_tx * vec) * sizeof(float);
+  return (((3 * g.k * g.k + 3) & ~3) + 3 * static_cast<size_t>(t.apply_rows) * (g.W + g.k - 1) + t.chan_tx * vec + g.C) * sizeof(float);
 }
-static size_t bwd_apply_smem(const Geo& g, int vec) { return (4 * static_cast<size_t>(g.C) + 2 * g.hidden + kBlock * vec) * sizeof(float); }
+static size_t bwd_apply_smem(const Geo& g, int vec) { return (5 * static_cast<size_t>(g.C) + 2 * g.hidden + kBlock * vec) * sizeof(float); }
+static size_t reduce1_smem(const Geo& g, int vec) { return (3 * static_cast<size_t>(g.C) + kBlock * vec) * sizeof(float); }
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -342,6 +344,11 @@ static int for_each_group(Args* args, const Sig* sigs, int n, Run run) {
     int m = 0;
     for (int j = l; j < n && m < kGroupMax; ++j)
       if (!done[j] && sigs[j] == sigs[l]) { grp[m++] = args[j]; done[j] = true; }
+    if (env_int("MGACBAM_LEVEL_ORDER", 1))
+      std::stable_sort(grp, grp + m, [](const Args& a, const Args& b) {
+        const int ca = a.g.C * a.t.chan_tx, cb = b.g.C * b.t.chan_tx;   // ~ channels per thread of the tile kernels
+        return ca > cb;
+      });
     if (int e = run(grp, m, sigs[l])) return e;
   }
   return 0;
@@ -415,8 +422,10 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
   auto fill = [&](auto blocks_of) { int tot = 0; for (int l = 0; l < n; ++l) { G.start[l] = tot; tot += blocks_of(lv[l]); } G.start[n] = tot; return tot; };
 
   if (stages & MGACBAM_BWD_REDUCE1) {  // 1. per-(b,c) and per-pixel reductions of gy*x
+    size_t smem = 0;
+    for (int l = 0; l < n; ++l) smem = std::max(smem, reduce1_smem(lv[l].g, sig.vec));
     const int grid = fill([&](const BwdArgs& a) { return xcd_grid(a.g.B, a.nt); });
-#define CALL_R1(Tt, Vv) LAUNCH((k_bwd_reduce1<Tt, Vv>), grid, 0, st, G)
+#define CALL_R1(Tt, Vv) LAUNCH((k_bwd_reduce1<Tt, Vv>), grid, smem, st, G)
     DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_R1);
 #undef CALL_R1
     if (int e = launch_status("k_bwd_reduce1")) return e;
