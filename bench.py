@@ -94,27 +94,46 @@ def make_plan(workload, device, seed):
 
 
 def time_kernels(plan, reps):
-    """Mean duration of every kernel group (all levels of one stage), measured with events on the launch stream."""
+    """Mean duration of each of the step's 7 launches, measured IN STEP ORDER (so every kernel sees the cache state the
+    previous one leaves, as in the real step): the step is issued eagerly `reps` times with an event before and after each
+    library call on the launch stream; elapsed(before, after) brackets exactly one kernel launch."""
     import torch
     from mga_yolo_amd import _lib
+    Bs, Fs = _lib.BWD_STAGES, _lib.FWD_STAGES
+    seq = [("fwd.pool", plan.forward, Fs["pool"]), ("fwd.chan", plan.forward, Fs["chan"]), ("fwd.apply", plan.forward, Fs["apply"]),
+           ("bwd.reduce1", plan.backward, Bs["reduce1"]), ("bwd.convT", plan.backward, Bs["convT"]),
+           # the two fused launches: streaming workgroups + role workgroups (dWsa partials / parameter gradients)
+           ("bwd.reduce2", plan.backward, Bs["reduce2"] | Bs["wsa"] | _lib.BWD_FUSE),
+           ("bwd.apply", plan.backward, Bs["params"] | Bs["apply"] | _lib.BWD_FUSE)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(seq) + 1)] for _ in range(reps)]
+    for _ in range(3):
+        for _, fn, mask in seq:
+            fn(mask)
+    torch.cuda.synchronize()
+    for r in range(reps):
+        ev[r][0].record()
+        for k, (_, fn, mask) in enumerate(seq):
+            fn(mask)
+            ev[r][k + 1].record()
+    torch.cuda.synchronize()
+    # the same eager step without the inner events: the difference, spread over the launches, is what the event records
+    # themselves cost on the stream (it is not kernel time and is subtracted)
+    o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    o0.record()
+    for r in range(reps):
+        for _, fn, mask in seq:
+            fn(mask)
+    o1.record()
+    torch.cuda.synchronize()
+    t_outer = o0.elapsed_time(o1) * 1e3 / reps
     out = {}
-    B = _lib.BWD_STAGES
-    todo = [("fwd." + k, plan.forward, v) for k, v in _lib.FWD_STAGES.items()] + [
-        ("bwd.reduce1", plan.backward, B["reduce1"]), ("bwd.convT", plan.backward, B["convT"]),
-        # the two fused launches of the step: streaming workgroups + role workgroups (dWsa partials / parameter gradients)
-        ("bwd.reduce2", plan.backward, B["reduce2"] | B["wsa"] | _lib.BWD_FUSE),
-        ("bwd.apply", plan.backward, B["params"] | B["apply"] | _lib.BWD_FUSE)]
-    for name, fn, mask in todo:
-        for _ in range(3):
-            fn(mask)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            fn(mask)
-        e1.record()
-        torch.cuda.synchronize()
-        out[name] = e0.elapsed_time(e1) * 1e3 / reps            # us per launch (one grouped launch covers P3+P4+P5)
+    keep = max(1, (3 * reps) // 4)
+    for k, (name, _, _) in enumerate(seq):
+        ts = sorted(ev[r][k].elapsed_time(ev[r][k + 1]) * 1e3 for r in range(reps))
+        out[name] = sum(ts[:keep]) / keep                       # mean of the fastest 75 % (drops host hiccups)
+    pad = max(0.0, (sum(out.values()) - t_outer) / len(seq))
+    out = {k: max(v - pad, 0.0) for k, v in out.items()}
+    out["_event_pad_us"] = pad
     return out
 
 
@@ -185,14 +204,25 @@ def main():
         plan.forward(S["chan"] | S["apply"])
         plan.backward()
 
+    def whole():
+        part_a()
+        part_b()
+
     if args.no_graph:
-        run_a, run_b = part_a, part_b
+        run_a, run_b, run_all = part_a, part_b, whole
+    elif world == 1:
+        g_all = plan.capture(whole)          # one graph per step: a graph boundary costs ~8 us on the device (rocprof trace)
+        run_a = run_b = None
+        run_all = g_all.replay
     else:
-        ga, gb = plan.capture(part_a), plan.capture(part_b)
-        run_a, run_b = ga.replay, gb.replay
+        ga, gb = plan.capture(part_a), plan.capture(part_b)   # split only where the gradient exchange has to be joined
+        run_a, run_b, run_all = ga.replay, gb.replay, None
 
     def step():
-        run_a()                  # N > 1: overlaps the all-reduce started at the end of the previous step
+        if world == 1:
+            run_all()
+            return
+        run_a()                  # overlaps the all-reduce started at the end of the previous step
         exchange.finish()        # averaged gradients of the previous step are complete before any parameter is read
         run_b()
         exchange.start()         # all-reduce of this step's flat gradient bucket on a side stream
@@ -225,6 +255,7 @@ def main():
     E = plan.elements()
     w = 4
     kernels = {}
+    event_pad = kt.pop("_event_pad_us")
     for name, us in kt.items():
         side, k = name.split(".")
         mult = (FWD_KERNEL_E if side == "fwd" else BWD_KERNEL_E).get(k)
@@ -244,11 +275,11 @@ def main():
     roofline = dict(bound="hbm", kernel=KERNEL_SYMBOL[dom], stage=dom, achieved=kernels[dom]["GBps"], peak=HBM_PEAK_GBPS, unit="GB/s",
                     frac=round(kernels[dom]["GBps"] / HBM_PEAK_GBPS, 4), traffic=traffic,
                     alg_bytes_per_launch=kernels[dom]["alg_bytes"], us=kernels[dom]["us"],
-                    note="one launch covers P3+P4+P5; duration = mean over back-to-back launches between two events on the launch stream")
+                    note="one launch covers P3+P4+P5; duration = mean elapsed time between an event recorded before and one after the launch, on the launch stream, with the step issued in order")
     step_alg = 8 * E * w                                           # forward 3*E*w + backward 5*E*w
     step_roof = dict(alg_bytes=step_alg, GBps=round(step_alg / (ms_per_step * 1e-3) / 1e9, 1),
                      frac=round(step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                     sum_kernel_us=round(sum(kt.values()), 1))
+                     sum_kernel_us=round(sum(kt.values()), 1), event_pad_us=round(event_pad, 2))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -260,7 +291,7 @@ def main():
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                     config=dict(workload=desc, batch_per_gpu=batch, global_batch=batch * world,
                                 levels=[list(s) for s in plan.shapes], parallelism=f"dp{world}",
-                                launch="eager" if args.no_graph else "hipGraph replay (2 graphs/step)",
+                                launch="eager" if args.no_graph else ("hipGraph replay, 1 graph/step" if world == 1 else "hipGraph replay, 2 graphs/step (split at the gradient-exchange join)"),
                                 grad_exchange=None if world == 1 else f"RCCL all-reduce of one {plan.grad_bucket.numel() * 4} B bucket per step, overlapped with the next step's parameter-free k_pool"),
                     roofline=roofline, step_roofline=step_roof, kernels=kernels, cpu_baseline=cpu,
                     lib=_lib.load().mgacbam_build_info().decode())

@@ -288,21 +288,32 @@ __device__ __forceinline__ void bwd_reduce2_body(const BwdArgs& A, const int bid
 #pragma unroll
   for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
 
-  for (int i = tx; i < nv; i += TX) {
-    float g0[VEC], g1[VEC];
-    int ci[VEC];
-    load_vec<float, VEC>(gp0 + static_cast<size_t>(i) * VEC, g0);
-    load_vec<float, VEC>(gp1 + static_cast<size_t>(i) * VEC, g1);
-    load_ivec<VEC>(cidx + static_cast<size_t>(i) * VEC, ci);
-    float xv[CPT][VEC];
+  constexpr int PF = 4;                                       // positions per lane per memory round (see k_pool)
+  for (int i0 = tx; i0 < nv; i0 += TX * PF) {
+    float g0[PF][VEC], g1[PF][VEC], xv[PF][CPT][VEC];
+    int ci[PF][VEC];
+    bool ok[PF];
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) load_vec<T, VEC>(xr[j] + static_cast<size_t>(i) * VEC, xv[j]);
+    for (int p = 0; p < PF; ++p) {
+      const int i = i0 + p * TX;
+      ok[p] = i < nv;
+      const size_t o = static_cast<size_t>(ok[p] ? i : nv - 1) * VEC;
+      load_vec<float, VEC>(gp0 + o, g0[p]);
+      load_vec<float, VEC>(gp1 + o, g1[p]);
+      load_ivec<VEC>(cidx + o, ci[p]);
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
+      for (int j = 0; j < CPT; ++j) load_vec<T, VEC>(xr[j] + o, xv[p][j]);
+    }
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const float wgt = g1[e] * invC + (ci[e] == cj[j] ? g0[e] : 0.f);   // mean backward + max backward
-        acc[j] += xv[j][e] * wgt;
+    for (int p = 0; p < PF; ++p) {
+      if (!ok[p]) continue;
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float wgt = g1[p][e] * invC + (ci[p][e] == cj[j] ? g0[p][e] : 0.f);   // mean backward + max backward
+          acc[j] += xv[p][j][e] * wgt;
+        }
       }
     }
   }

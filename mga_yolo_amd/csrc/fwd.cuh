@@ -55,34 +55,48 @@ __device__ __forceinline__ void pool_body(const FwdArgs& A, const int bid, float
   for (int j = 0; j < CPT; ++j) { sx[j] = 0.f; sxs[j] = 0.f; vmax[j] = -FLT_MAX; imax[j] = 0; }
   float ssum = 0.f;
 
-  for (int i = tx; i < nv; i += TX) {
-    float s[VEC];
-    bool sel[VEC];
-    if (HAS_MASK) {
-      float m[VEC];
-      load_vec<float, VEC>(mb + static_cast<size_t>(i) * VEC, m);
+  // PF positions per lane are requested per round: a lane's sweep is a chain of dependent memory rounds (each ~2.5 us
+  // under load), so the kernel cannot finish before rounds x latency -- fewer, fatter rounds (profiles/ notes, membw).
+  constexpr int PF = 4;
+  for (int i0 = tx; i0 < nv; i0 += TX * PF) {
+    float m[PF][VEC], xv[PF][CPT][VEC];
+    bool ok[PF];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        s[e] = g.use_sigmoid ? sigmoid_fast(m[e]) : m[e];   // masked_cbam.py:93-94
-        sel[e] = s[e] > 0.5f;                               // masked_cbam.py:116
-        ssum += s[e];
-      }
-    } else {
+    for (int p = 0; p < PF; ++p) {
+      const int i = i0 + p * TX;
+      ok[p] = i < nv;
+      const size_t o = static_cast<size_t>(ok[p] ? i : nv - 1) * VEC;
+      if (HAS_MASK) load_vec<float, VEC>(mb + o, m[p]);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) { s[e] = 0.f; sel[e] = true; }   // masked_cbam.py:138 (zero plane)
+      for (int j = 0; j < CPT; ++j) load_vec<T, VEC>(xr[j] + o, xv[p][j]);
     }
-    if (writes_plane) store_vec<float, VEC>(splane + static_cast<size_t>(i) * VEC, s);
-    float xv[CPT][VEC];
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) load_vec<T, VEC>(xr[j] + static_cast<size_t>(i) * VEC, xv[j]);
+    for (int p = 0; p < PF; ++p) {
+      if (!ok[p]) continue;
+      const int i = i0 + p * TX;
+      float s[VEC];
+      bool sel[VEC];
+      if (HAS_MASK) {
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
+        for (int e = 0; e < VEC; ++e) {
+          s[e] = g.use_sigmoid ? sigmoid_fast(m[p][e]) : m[p][e];   // masked_cbam.py:93-94
+          sel[e] = s[e] > 0.5f;                                     // masked_cbam.py:116
+          ssum += s[e];
+        }
+      } else {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const float v = xv[j][e];
-        sx[j] += v;
-        if (HAS_MASK) sxs[j] += v * s[e];
-        if (sel[e] && v > vmax[j]) { vmax[j] = v; imax[j] = i * VEC + e; }   // strict > : first max wins
+        for (int e = 0; e < VEC; ++e) { s[e] = 0.f; sel[e] = true; }   // masked_cbam.py:138 (zero plane)
+      }
+      if (writes_plane) store_vec<float, VEC>(splane + static_cast<size_t>(i) * VEC, s);
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float v = xv[p][j][e];
+          sx[j] += v;
+          if (HAS_MASK) sxs[j] += v * s[e];
+          if (sel[e] && v > vmax[j]) { vmax[j] = v; imax[j] = i * VEC + e; }   // strict > : first max wins
+        }
       }
     }
   }
