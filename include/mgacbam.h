@@ -26,10 +26,19 @@
 extern "C" {
 #endif
 
-#define MGACBAM_ABI_VERSION 4
+#define MGACBAM_ABI_VERSION 5
 #define MGACBAM_MAX_LEVELS 8          /* P3/P4/P5 need 3 */
 
 enum { MGACBAM_F32 = 0, MGACBAM_F16 = 1, MGACBAM_BF16 = 2 };
+
+/* Level flags.  The forward can save P[b,j,hw] = sum_c W1[j,c] x[b,c,hw] (hidden <= MGACBAM_PROJ_MAX_HIDDEN planes per sample)
+ * while it streams x anyway; the backward then forms the masked-average part of dL/dmask, sum_c g_avg[b,c] x[b,c,hw] =
+ * sum_j g_h[b,j] P[b,j,hw], from those planes and its largest kernel does not read x at all (3 -> 2 feature-sized streams).
+ * Set MGACBAM_FWD_SAVE_PROJ in the forward of a step whose backward will ask for gmask, and MGACBAM_BWD_HAVE_PROJ in that
+ * backward.  Levels with a larger hidden size ignore the flags and read x. */
+#define MGACBAM_PROJ_MAX_HIDDEN 4
+enum { MGACBAM_FWD_SAVE_PROJ = 1 };
+enum { MGACBAM_BWD_HAVE_PROJ = 1 };
 
 enum {
   MGACBAM_E_NULL = -1,        /* required pointer is NULL */
@@ -68,6 +77,7 @@ typedef struct mgacbam_fwd_level {
   mgacbam_params_t p;
   int32_t B, C, H, W;
   int32_t dtype;
+  int32_t flags;             /* MGACBAM_FWD_* */
 } mgacbam_fwd_level_t;
 
 /* One pyramid level of a backward call: replaces what autograd derives for the block. */
@@ -88,6 +98,7 @@ typedef struct mgacbam_bwd_level {
   mgacbam_params_t p;
   int32_t B, C, H, W;
   int32_t dtype;
+  int32_t flags;             /* MGACBAM_BWD_HAVE_PROJ */
 } mgacbam_bwd_level_t;
 
 /* Named regions inside ctx (byte offsets), for stage-wise tests and tooling.  All fp32 unless noted. */
@@ -106,6 +117,7 @@ typedef struct mgacbam_ctx_layout {
   int64_t planes;   /* (B,3,HW) [max_c u, mean_c u, sigma(mask)]           masked_cbam.py:146 */
   int64_t cidx;     /* (B,HW)   int32: first arg-max channel of u          masked_cbam.py:135 */
   int64_t sa;       /* (B,HW)   spatial gate                              masked_cbam.py:147 */
+  int64_t proj;     /* (B,hid,HW) W1-projection of x, only when hid <= MGACBAM_PROJ_MAX_HIDDEN (else empty)  */
   int64_t total;    /* == mgacbam_ctx_bytes()                                                 */
 } mgacbam_ctx_layout_t;
 

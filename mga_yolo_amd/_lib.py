@@ -8,13 +8,14 @@ import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmgacbam.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LEVELS = 8
 F32, F16, BF16 = 0, 1, 2
 # stage bit masks (include/mgacbam.h)
 FWD_STAGES = dict(pool=1, chan=2, apply=4)
 BWD_STAGES = dict(reduce1=1, convT=2, reduce2=4, wsa=8, params=16, apply=32)
 BWD_FUSE = 64
+FWD_SAVE_PROJ, BWD_HAVE_PROJ, PROJ_MAX_HIDDEN = 1, 1, 4
 FWD_ALL, BWD_PARAMS, BWD_INPUTS, BWD_ALL = 7, 31, 32, 127
 
 _c_float_p = C.POINTER(C.c_float)
@@ -30,7 +31,7 @@ class Params(C.Structure):                       # mgacbam_params_t
 class FwdLevel(C.Structure):                     # mgacbam_fwd_level_t
     _fields_ = [("x", C.c_void_p), ("mask", C.c_void_p), ("y", C.c_void_p), ("ctx", C.c_void_p),
                 ("p", Params), ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("dtype", C.c_int32)]
+                ("dtype", C.c_int32), ("flags", C.c_int32)]
 
 
 class BwdLevel(C.Structure):                     # mgacbam_bwd_level_t
@@ -39,10 +40,10 @@ class BwdLevel(C.Structure):                     # mgacbam_bwd_level_t
                 ("gw1", C.c_void_p), ("gb1", C.c_void_p), ("gw2", C.c_void_p), ("gb2", C.c_void_p),
                 ("gwsa", C.c_void_p), ("gbeta", C.c_void_p),
                 ("p", Params), ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("dtype", C.c_int32)]
+                ("dtype", C.c_int32), ("flags", C.c_int32)]
 
 
-CTX_FIELDS = ("S", "use", "den", "avg", "mx", "mavg", "valid", "amax", "h_avg", "h_mx", "ca", "planes", "cidx", "sa", "total")
+CTX_FIELDS = ("S", "use", "den", "avg", "mx", "mavg", "valid", "amax", "h_avg", "h_mx", "ca", "planes", "cidx", "sa", "proj", "total")
 
 
 class CtxLayout(C.Structure):                    # mgacbam_ctx_layout_t

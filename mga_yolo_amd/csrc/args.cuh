@@ -10,7 +10,9 @@ struct Geo {
   int hidden, k;
   int use_sigmoid;
   float thr, eps;
+  int proj_h;      // > 0: W1-projection planes of x are saved (forward) / available (backward); = hidden (<= kProjMax)
 };
+constexpr int kProjMax = 4;   // MGACBAM_PROJ_MAX_HIDDEN
 
 // saved statistics (device pointers into the caller's ctx buffer) -- see mgacbam_ctx_layout_t
 struct CtxPtrs {
@@ -19,6 +21,7 @@ struct CtxPtrs {
   int* valid; int* amax;
   float* h_avg; float* h_mx; float* ca;
   float* planes; int* cidx; float* sa;
+  float* proj;     // (B, hidden, HW) when hidden <= kProjMax
 };
 
 struct ParamPtrs { const float* w1; const float* b1; const float* w2; const float* b2; const float* wsa; const float* beta; };
@@ -72,8 +75,10 @@ struct BwdArgs {
 static inline size_t align16(size_t v) { return (v + 15) & ~size_t(15); }
 
 // One launch covers up to kGroupMax pyramid levels: workgroup ids [start[l], start[l+1]) belong to level l.
-// P3+P4+P5 of YOLOv8n are 52+26+13 MB -- alone, P5 cannot fill 256 CUs and every extra launch costs ~2.7 us of
-// dependent-kernel boundary, so each stage is ONE launch whose grid is the concatenation of the levels' grids.
+// P3+P4+P5 of YOLOv8n are 52+26+13 MB -- alone, P5 cannot fill 256 CUs and every extra launch costs ~2.5 us of
+// dependent-kernel boundary, so each stage is ONE launch whose grid is the concatenation of the levels' grids, the level
+// whose workgroups run longest FIRST (api: for_each_group).  Interleaving the levels round-robin instead was measured and
+// is worse (k_bwd_reduce1 30 -> 43 us): the long, latency-bound P5 workgroups then also sit in the last round = the tail.
 constexpr int kGroupMax = 4;
 template <typename Args>
 struct Group {

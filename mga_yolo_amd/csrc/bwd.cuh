@@ -540,13 +540,15 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
 #pragma unroll
   for (int e = 0; e < VEC; ++e) accp[e] = 0.f;
 
+  // With the W1-projection planes saved by k_chan, sum_c g_avg[b,c]*x[b,c,hw] = sum_j g_h[b,j]*P[b,j,hw]: x is not read.
+  const bool need_x = GMASK && g.proj_h == 0;
   // first feature vectors are requested before the prologue so its latency overlaps theirs
   float g0v[UN][VEC], x0v[UN][VEC];
 #pragma unroll
   for (int u = 0; u < UN; ++u) {
     const size_t co = static_cast<size_t>(min(ty + u * TY, g.C - 1)) * g.HW;
     load_vec<T, VEC>(gp + co, g0v[u]);
-    if (GMASK) load_vec<T, VEC>(xp + co, x0v[u]);
+    if (GMASK) { if (need_x) load_vec<T, VEC>(xp + co, x0v[u]); }
   }
 
   // ---- prologue: q[c] and K_b for this sample -------------------------------------------------------------------
@@ -610,7 +612,7 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
       r += q.y * wA[e] + q.w;
       r += (am == e) ? q.z : 0.f;
       ov[e] = r;
-      if (GMASK) accp[e] += q.y * xv[e];
+      if (GMASK) { if (need_x) accp[e] += q.y * xv[e]; }
     }
     if (active) store_vec_stream<T, VEC>(op + static_cast<size_t>(c) * g.HW, ov, A.t.nt_stores);
   };
@@ -623,18 +625,30 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
   for (int c = ty + UN * TY; c < g.C; c += TY) {
     float gv[VEC], xv[VEC];
     load_vec<T, VEC>(gp + static_cast<size_t>(c) * g.HW, gv);
-    if (GMASK) load_vec<T, VEC>(xp + static_cast<size_t>(c) * g.HW, xv);
+    if (GMASK) { if (need_x) load_vec<T, VEC>(xp + static_cast<size_t>(c) * g.HW, xv); }
     emit(gv, xv, c);
   }
   if (GMASK) {
+    if (need_x) {
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) sm[tid * VEC + e] = accp[e];
-    __syncthreads();
+      for (int e = 0; e < VEC; ++e) sm[tid * VEC + e] = accp[e];
+      __syncthreads();
+    }
     if (ty == 0 && active) {
-      for (int r = 1; r < TY; ++r) {
-        const int o = (r * TX + tx) * VEC;
+      if (need_x) {
+        for (int r = 1; r < TY; ++r) {
+          const int o = (r * TX + tx) * VEC;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) accp[e] += sm[o + e];
+          for (int e = 0; e < VEC; ++e) accp[e] += sm[o + e];
+        }
+      } else {
+        for (int j = 0; j < g.proj_h; ++j) {                   // sum_j g_h_avg[b,j] * P[b,j,hw]
+          float pv[VEC];
+          load_vec<float, VEC>(A.c.proj + (static_cast<size_t>(b) * g.proj_h + j) * g.HW + static_cast<size_t>(i) * VEC, pv);
+          const float gh = s_gh[j];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) accp[e] += gh * pv[e];
+        }
       }
       float g2[VEC], gm[VEC];
       load_vec<float, VEC>(A.s.gplanes + (static_cast<size_t>(b) * 3 + 2) * g.HW + static_cast<size_t>(i) * VEC, g2);

@@ -203,11 +203,14 @@ __device__ __forceinline__ void mlp_gate_to_lds(const FwdArgs& A, const int b, c
 //   workgroup = (sample b, tile of TX vectors along H*W); row ty handles channels ty, ty+TY, ...; the TY partial
 //   (max, idx, sum) triples are combined through LDS.  Prologue: the sample's MLP (above); the first UN feature
 //   vectors of every lane are requested BEFORE it so the two latencies overlap.
-//   LDS: [2C scratch][2h][C ca][3*256*VEC combine]
+//   PROJ (training steps that will want dL/dmask): while x streams through, also accumulate the W1-projection planes
+//   P[b,j,hw] = sum_c W1[j,c] x[b,c,hw] (hidden <= kProjMax), so that k_bwd_apply never has to read x (see bwd.cuh).
+//   LDS: [2C scratch][2h][C ca][C*kProjMax W1^T (PROJ)][4*256*VEC combine]
 // ---------------------------------------------------------------------------------------------
-template <typename T, int VEC>
+template <typename T, int VEC, bool PROJ>
 __device__ __forceinline__ void chan_body(const FwdArgs& A, const int bid, float* smem) {
   constexpr int UN = 4;
+  constexpr int HP = kProjMax;
   const Geo& g = A.g;
   const int tid = threadIdx.x;
   const int TX = A.t.chan_tx, lt = ilog2(TX);
@@ -228,37 +231,59 @@ __device__ __forceinline__ void chan_body(const FwdArgs& A, const int bid, float
   float* s_in = smem;
   float* s_h = smem + 2 * g.C;
   float* s_ca = s_h + 2 * g.hidden;
-  float* sm = s_ca + g.C;
-  mlp_gate_to_lds(A, b, tile == 0, s_in, s_h, s_ca);
+  float* s_w1t = s_ca + g.C;                                   // [c][HP], zero padded past hidden
+  const bool proj = PROJ && g.proj_h > 0;
+  float* sm = s_w1t + (PROJ ? g.C * HP : 0);
+  if (proj) {
+    for (int idx = tid; idx < g.C * HP; idx += kBlock) {
+      const int c = idx / HP, j = idx - c * HP;
+      s_w1t[idx] = j < g.proj_h ? A.p.w1[static_cast<size_t>(j) * g.C + c] : 0.f;
+    }
+  }
+  mlp_gate_to_lds(A, b, tile == 0, s_in, s_h, s_ca);           // (its barriers also publish s_w1t)
 
   float vmax[VEC], vsum[VEC];
   int vidx[VEC];
+  float accP[PROJ ? HP : 1][VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { vmax[e] = -INFINITY; vsum[e] = 0.f; vidx[e] = ty; }
 #pragma unroll
-  for (int u = 0; u < UN; ++u) {
-    const int c = ty + u * TY;
-    if (c < g.C) {
-      const float cac = s_ca[c];
+  for (int j = 0; j < (PROJ ? HP : 1); ++j)
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const float uu = x0[u][e] * cac;                     // masked_cbam.py:130
-        vsum[e] += uu;
-        if (uu > vmax[e]) { vmax[e] = uu; vidx[e] = c; }
+    for (int e = 0; e < VEC; ++e) accP[j][e] = 0.f;
+  auto consume = [&](const float (&xv)[VEC], int c) {
+    const float cac = s_ca[c];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float uu = xv[e] * cac;                          // masked_cbam.py:130
+      vsum[e] += uu;
+      if (uu > vmax[e]) { vmax[e] = uu; vidx[e] = c; }
+    }
+    if (PROJ) {
+      if (proj) {
+        float w[HP];
+#pragma unroll
+        for (int q4 = 0; q4 < HP / 4; ++q4) {
+          const float4 wv = *reinterpret_cast<const float4*>(s_w1t + c * HP + 4 * q4);
+          w[4 * q4] = wv.x; w[4 * q4 + 1] = wv.y; w[4 * q4 + 2] = wv.z; w[4 * q4 + 3] = wv.w;
+        }
+#pragma unroll
+        for (int j = 0; j < HP; ++j)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) accP[j][e] += w[j] * xv[e];
       }
     }
+  };
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const int c = ty + u * TY;
+    if (c < g.C) consume(x0[u], c);
   }
 #pragma unroll 4
   for (int c = ty + UN * TY; c < g.C; c += TY) {
     float xv[VEC];
     load_vec<T, VEC>(xp + static_cast<size_t>(c) * g.HW, xv);
-    const float cac = s_ca[c];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const float uu = xv[e] * cac;
-      vsum[e] += uu;
-      if (uu > vmax[e]) { vmax[e] = uu; vidx[e] = c; }
-    }
+    consume(xv, c);
   }
   float* smax = sm;
   int* sidx = reinterpret_cast<int*>(sm + kBlock * VEC);
@@ -285,14 +310,43 @@ __device__ __forceinline__ void chan_body(const FwdArgs& A, const int bid, float
     store_vec<float, VEC>(pl + g.HW, pavg);
     store_ivec<VEC>(A.c.cidx + static_cast<size_t>(b) * g.HW + static_cast<size_t>(i) * VEC, vidx);
   }
+  if (PROJ) {
+    if (proj) {                                                // TY partials of the projection planes, 4 planes per LDS round
+#pragma unroll
+      for (int half = 0; half < HP / 4; ++half) {
+        if (half * 4 >= g.proj_h) break;
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) sm[(jj * kBlock + tid) * VEC + e] = accP[half * 4 + jj][e];
+        __syncthreads();
+        if (ty == 0 && active) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int j = half * 4 + jj;
+            if (j < g.proj_h) {
+              float pv[VEC];
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) pv[e] = accP[j][e];
+              for (int r = 1; r < TY; ++r)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) pv[e] += sm[(jj * kBlock + r * TX + tx) * VEC + e];
+              store_vec<float, VEC>(A.c.proj + (static_cast<size_t>(b) * g.proj_h + j) * g.HW + static_cast<size_t>(i) * VEC, pv);
+            }
+          }
+        }
+      }
+    }
+  }
 }
 
-template <typename T, int VEC>
+template <typename T, int VEC, bool PROJ>
 __global__ __launch_bounds__(kBlock) void k_chan(const Group<FwdArgs> G) {
   extern __shared__ __align__(16) float smem[];
   int local;
   const int l = find_level(G, blockIdx.x, local);
-  chan_body<T, VEC>(G.lv[l], local, smem);
+  chan_body<T, VEC, PROJ>(G.lv[l], local, smem);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -65,6 +65,7 @@ static void ctx_layout(int B, int C, int H, int W, int hidden, mgacbam_ctx_layou
   L->planes = take(static_cast<size_t>(B) * 3 * HW);
   L->cidx = take(static_cast<size_t>(B) * HW);
   L->sa = take(static_cast<size_t>(B) * HW);
+  L->proj = take(hidden <= MGACBAM_PROJ_MAX_HIDDEN ? static_cast<size_t>(B) * hidden * HW : 0);
   L->total = static_cast<int64_t>(o);
 }
 
@@ -79,6 +80,7 @@ static CtxPtrs ctx_ptrs(void* base, int B, int C, int H, int W, int hidden) {
   c.h_avg = reinterpret_cast<float*>(p + L.h_avg); c.h_mx = reinterpret_cast<float*>(p + L.h_mx);
   c.ca = reinterpret_cast<float*>(p + L.ca);
   c.planes = reinterpret_cast<float*>(p + L.planes); c.cidx = reinterpret_cast<int*>(p + L.cidx); c.sa = reinterpret_cast<float*>(p + L.sa);
+  c.proj = reinterpret_cast<float*>(p + L.proj);
   return c;
 }
 
@@ -215,6 +217,7 @@ static Geo make_geo(int B, int C, int H, int W, const mgacbam_params_t& p) {
   Geo g;
   g.B = B; g.C = C; g.H = H; g.W = W; g.HW = H * W; g.hidden = p.hidden; g.k = p.k;
   g.use_sigmoid = p.use_sigmoid_mask; g.thr = p.tiny_thr; g.eps = p.eps;
+  g.proj_h = 0;
   return g;
 }
 static ParamPtrs make_params(const mgacbam_params_t& p) { return ParamPtrs{p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta}; }
@@ -226,8 +229,10 @@ static int check_params(const mgacbam_params_t& p) {
 // Levels that share every compile-time property of the kernels (element type, vector width, mask / no mask,
 // conv size, dL/dmask wanted) are launched together: one grid per stage, the levels' grids concatenated.
 struct Sig {
-  int dtype, vec, has_mask, k, gmask;
-  bool operator==(const Sig& o) const { return dtype == o.dtype && vec == o.vec && has_mask == o.has_mask && k == o.k && gmask == o.gmask; }
+  int dtype, vec, has_mask, k, gmask, proj;
+  bool operator==(const Sig& o) const {
+    return dtype == o.dtype && vec == o.vec && has_mask == o.has_mask && k == o.k && gmask == o.gmask && proj == o.proj;
+  }
 };
 
 // channels per thread for the row-sweep kernels, uniform over a group: the largest of {4,2,1} that still gives the
@@ -263,7 +268,9 @@ static size_t wsa_smem(const Tune& t, int k) {
 }
 static size_t params_smem(const Geo& g) { return (3 * static_cast<size_t>(g.B) + 2 * kBlock) * sizeof(float); }
 static int params_blocks(const Geo& g) { return g.hidden + (g.C + kBlock - 1) / kBlock + (3 * g.k * g.k + 3) / 4 + 1; }
-static size_t chan_smem(const Geo& g, int vec) { return (3 * static_cast<size_t>(g.C) + 2 * g.hidden + 3 * kBlock * vec) * sizeof(float); }
+static size_t chan_smem(const Geo& g, int vec, bool proj) {
+  return (3 * static_cast<size_t>(g.C) + 2 * g.hidden + (proj ? static_cast<size_t>(g.C) * kProjMax : 0) + 4 * kBlock * vec) * sizeof(float);
+}
 static size_t apply_smem(const Geo& g, const Tune& t, int vec) {
   return (((3 * g.k * g.k + 3) & ~3) + 3 * static_cast<size_t>(t.apply_rows) * (g.W + g.k - 1) + t.chan_tx * vec + g.C) * sizeof(float);
 }
@@ -287,7 +294,9 @@ static int forward_args(const mgacbam_fwd_level_t& L, FwdArgs& A, Sig& sig) {
   A.p = make_params(L.p);
   A.g = make_geo(L.B, L.C, L.H, L.W, L.p);
   A.t = choose_tune(L.B, L.C, L.H, L.W, L.p.k);
-  sig = Sig{L.dtype, VEC, L.mask != nullptr, L.p.k, 0};
+  const int proj = (L.flags & MGACBAM_FWD_SAVE_PROJ) && L.mask != nullptr;
+  A.g.proj_h = (proj && L.p.hidden <= MGACBAM_PROJ_MAX_HIDDEN) ? L.p.hidden : 0;
+  sig = Sig{L.dtype, VEC, L.mask != nullptr, L.p.k, 0, proj};
   return 0;
 }
 
@@ -309,9 +318,9 @@ static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStre
   }
   if (stages & MGACBAM_FWD_CHAN) {  // 2. shared MLP + channel gate (prologue), channel max / mean planes
     size_t smem = 0;
-    for (int l = 0; l < n; ++l) smem = std::max(smem, chan_smem(lv[l].g, sig.vec));
+    for (int l = 0; l < n; ++l) smem = std::max(smem, chan_smem(lv[l].g, sig.vec, sig.proj));
     const int grid = fill([&](const FwdArgs& a) { return xcd_grid(a.g.B, chan_tiles(a.t, a.g.H, a.g.W)); });
-#define CALL_CHAN(Tt, Vv) LAUNCH((k_chan<Tt, Vv>), grid, smem, st, G)
+#define CALL_CHAN(Tt, Vv) if (sig.proj) LAUNCH((k_chan<Tt, Vv, true>), grid, smem, st, G); else LAUNCH((k_chan<Tt, Vv, false>), grid, smem, st, G)
     DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_CHAN);
 #undef CALL_CHAN
     if (int e = launch_status("k_chan")) return e;
@@ -405,7 +414,9 @@ static int backward_args(const mgacbam_bwd_level_t& L, BwdArgs& A, Sig& sig) {
   A.nwsa = A.g.B * wsa_tiles(A.t, A.g.H, A.g.W);
   A.npg = params_blocks(A.g);
   A.ncg = 0;
-  sig = Sig{L.dtype, VEC, L.mask != nullptr, L.p.k, L.gmask != nullptr};
+  const int proj = (L.flags & MGACBAM_BWD_HAVE_PROJ) && L.gmask != nullptr;
+  A.g.proj_h = (proj && L.p.hidden <= MGACBAM_PROJ_MAX_HIDDEN) ? L.p.hidden : 0;
+  sig = Sig{L.dtype, VEC, L.mask != nullptr, L.p.k, L.gmask != nullptr, proj};
   return 0;
 }
 

@@ -10,6 +10,7 @@ Device tensors never take any other path: a missing library raises (``_lib.Libra
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -29,6 +30,7 @@ class BlockConfig:
 
 
 _DTYPES = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+_USE_PROJ = bool(int(os.environ.get("MGACBAM_PROJ", "0")))
 SLOTS = 8  # tensors per level in the flat argument list: x, mask, w1, b1, w2, b2, wsa, beta
 
 
@@ -91,9 +93,13 @@ class _PyramidFn(torch.autograd.Function):
             L.x, L.mask, L.y, L.ctx = xc.data_ptr(), (None if m32 is None else m32.data_ptr()), y.data_ptr(), cbuf.data_ptr()
             L.p = _params_struct(pc, cfg)
             L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[x.dtype]
+            # opt-in (MGACBAM_PROJ=1): the backward of this call will want dL/dmask, let the forward save the W1-projection
+            # planes for it.  Off by default: at YOLOv8n sizes what k_bwd_apply saves (x of P3) k_chan pays back
+            proj = _USE_PROJ and mask is not None and mask.requires_grad and torch.is_grad_enabled()
+            L.flags = _lib.FWD_SAVE_PROJ if proj else 0
             keep += [xc, m32, cbuf, *pc]
             outs.append(y)
-            meta.append((None if mask is None else (mask.dtype, tuple(mask.shape))))
+            meta.append(((None if mask is None else (mask.dtype, tuple(mask.shape))), proj))
         with torch.cuda.device(dev):
             _lib.check(lib.mgacbam_forward(levels, n, torch.cuda.current_stream(dev).cuda_stream), "mgacbam_forward")
         ctx.save_for_backward(*keep)
@@ -128,9 +134,10 @@ class _PyramidFn(torch.autograd.Function):
             L.gw1, L.gb1, L.gw2, L.gb2, L.gwsa, L.gbeta = (t.data_ptr() for t in pg)
             L.p = _params_struct(pc, cfg)
             L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[xc.dtype]
+            L.flags = _lib.BWD_HAVE_PROJ if ctx.meta[l][1] else 0
             hold += [gy, scratch]
             if gmask is not None:
-                mdtype, mshape = ctx.meta[l]
+                mdtype, mshape = ctx.meta[l][0]
                 gmask = gmask.reshape(mshape).to(mdtype)
             grads += [gx, gmask, *pg]
         with torch.cuda.device(dev):
@@ -156,7 +163,7 @@ def mask_cbam(x: torch.Tensor, mask: Optional[torch.Tensor], w1, b1, w2, b2, wsa
 # ---------------------------------------------------------------------------------------------------------
 # inspection helpers (tests / tooling): run the forward library call and view the saved statistics by name
 # ---------------------------------------------------------------------------------------------------------
-def forward_with_ctx(x, mask, params, cfg: BlockConfig):
+def forward_with_ctx(x, mask, params, cfg: BlockConfig, save_proj: bool = True):
     """-> (y, {name: tensor view into ctx}) without autograd; names follow mgacbam_ctx_layout_t."""
     lib = _lib.load()
     _check_level(x, mask, params, cfg)
@@ -171,6 +178,7 @@ def forward_with_ctx(x, mask, params, cfg: BlockConfig):
     L.x, L.mask, L.y, L.ctx = xc.data_ptr(), (None if m32 is None else m32.data_ptr()), y.data_ptr(), cbuf.data_ptr()
     L.p = _params_struct(pc, cfg)
     L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[x.dtype]
+    L.flags = _lib.FWD_SAVE_PROJ if (save_proj and mask is not None) else 0
     with torch.cuda.device(x.device):
         _lib.check(lib.mgacbam_forward(lv, 1, torch.cuda.current_stream(x.device).cuda_stream), "mgacbam_forward")
     return y, ctx_views(cbuf, B, Cc, H, W, cfg.hidden)
@@ -181,6 +189,8 @@ def ctx_views(cbuf: torch.Tensor, B, Cc, H, W, hidden) -> dict:
     HW = H * W
     shapes = dict(S=(B,), use=(B,), den=(B,), avg=(B, Cc), mx=(B, Cc), mavg=(B, Cc), valid=(B, Cc), amax=(B, Cc),
                   h_avg=(B, hidden), h_mx=(B, hidden), ca=(B, Cc), planes=(B, 3, HW), cidx=(B, HW), sa=(B, HW))
+    if hidden <= _lib.PROJ_MAX_HIDDEN:
+        shapes["proj"] = (B, hidden, HW)
     ints = {"valid", "amax", "cidx"}
     out = {}
     for name, shp in shapes.items():

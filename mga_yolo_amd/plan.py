@@ -23,7 +23,7 @@ PARAM_NAMES = ("w1", "b1", "w2", "b2", "wsa", "beta")
 class PyramidPlan:
     def __init__(self, shapes: Sequence[Tuple[int, int, int, int]], params: Sequence[Sequence[torch.Tensor]],
                  cfgs: Sequence[BlockConfig], dtype: torch.dtype = torch.float32, device="cuda",
-                 with_mask: bool = True, want_gmask: bool = True):
+                 with_mask: bool = True, want_gmask: bool = True, use_proj: bool = False):
         assert len(shapes) == len(params) == len(cfgs) and 1 <= len(shapes) <= _lib.MAX_LEVELS
         self.lib = _lib.load()
         self.device = torch.device(device)
@@ -55,11 +55,13 @@ class PyramidPlan:
             F.x, F.mask, F.y, F.ctx = ptr(self.x[l]), ptr(self.mask[l]), ptr(self.y[l]), ptr(self.ctx[l])
             F.p = _params_struct(ps, cfg)
             F.B, F.C, F.H, F.W, F.dtype = B, C, H, W, _DTYPES[dtype]
+            F.flags = _lib.FWD_SAVE_PROJ if (with_mask and want_gmask and use_proj) else 0
             Bw.x, Bw.mask, Bw.gy, Bw.ctx, Bw.scratch = ptr(self.x[l]), ptr(self.mask[l]), ptr(self.gy[l]), ptr(self.ctx[l]), ptr(self.scratch[l])
             Bw.gx, Bw.gmask = ptr(self.gx[l]), ptr(self.gmask[l])
             Bw.gw1, Bw.gb1, Bw.gw2, Bw.gb2, Bw.gwsa, Bw.gbeta = (v.data_ptr() for v in views)
             Bw.p = _params_struct(ps, cfg)
             Bw.B, Bw.C, Bw.H, Bw.W, Bw.dtype = B, C, H, W, _DTYPES[dtype]
+            Bw.flags = _lib.BWD_HAVE_PROJ if (with_mask and want_gmask and use_proj) else 0
 
     # ------------------------------------------------------------------ library calls on the current stream
     def _stream(self):

@@ -78,6 +78,8 @@ def test_forward_stages_vs_oracle(F, name):
         pass
     same("cidx", v["cidx"], c.cidx)
     close("sa", v["sa"], c.sa)
+    if "proj" in v and d["mask"] is not None:    # W1-projection planes saved for the backward (hidden <= 8)
+        close("proj", v["proj"], torch.einsum("jc,bcn->bjn", p.w1, d["x"].reshape(B, C, H * W)))
     close("y", y, y_o)
     close("y_vs_reference", y, d["out"]["y"])
     assert not report, f"{name}: " + "; ".join(report)
@@ -279,3 +281,39 @@ def test_native_library_is_loaded_in_this_process():
     _lib.load()
     maps = open("/proc/self/maps").read()
     assert "libmgacbam.so" in maps
+
+
+@pytest.mark.parametrize("want_gmask,use_proj", [(True, True), (True, False), (False, False)])
+def test_plan_executor_matches_oracle_with_and_without_projection_planes(F, want_gmask, use_proj):
+    """PyramidPlan (the graph-capturable executor): the backward that takes dL/dmask from the saved W1-projection planes
+    (no x read in k_bwd_apply) and the one that re-reads x must both match the oracle; levels with hidden > 8 (C=256) always re-read."""
+    from mga_yolo_amd.plan import PyramidPlan
+    shapes = [(4, 64, 16, 16), (4, 128, 8, 8), (4, 256, 4, 4)]
+    data, params, cfgs = [], [], []
+    for l, (B, C, H, W) in enumerate(shapes):
+        x, mask, gy = synth(B, C, H, W, seed=50 + l, mask_kind="mixed")
+        p = O.Params.default_init(C, seed=l)
+        p.beta.fill_(-0.4)
+        data.append((x, mask, gy, p))
+        params.append((p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta))
+        cfgs.append(F.BlockConfig(hidden=p.w1.shape[0]))
+    plan = PyramidPlan(shapes, params, cfgs, want_gmask=want_gmask, use_proj=use_proj)
+    for l, (x, mask, gy, _) in enumerate(data):
+        plan.x[l].copy_(x); plan.mask[l].copy_(mask); plan.gy[l].copy_(gy)
+    g = plan.capture(lambda: (plan.forward(), plan.backward()))
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    for l, (x, mask, gy, p) in enumerate(data):
+        y_o, c = O.forward(x, mask, p)
+        g_o = O.backward(gy, x, mask, p, O.Config(), c)
+        assert rel_err(plan.y[l], y_o) < TOL and rel_err(plan.gx[l], g_o["gx"]) < TOL, l
+        if want_gmask:
+            assert rel_err(plan.gmask[l], g_o["gmask"]) < TOL, l
+        for k, v in plan.named_param_grads(l).items():
+            assert rel_err(v, g_o[k]) < TOL, (l, k)
+    # split form (parameter gradients first, then input gradients) gives the same bits as the fused backward
+    ref = [t.clone() for t in plan.gx] + [plan.grad_bucket.clone()]
+    plan.forward(); plan.backward_params(); plan.backward_inputs()
+    torch.cuda.synchronize()
+    for a, b in zip(ref, list(plan.gx) + [plan.grad_bucket]):
+        assert torch.equal(a, b)
