@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the bounded CPU-baseline sample")
     ap.add_argument("--kernel-reps", type=int, default=30)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for rehearsing the multi-rank code path on one GPU)")
     return ap.parse_args()
 
 
@@ -186,11 +187,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     plan, desc, batch = make_plan(args.workload, device, seed=1234 + rank)
     exchange = GradExchange(plan.grad_bucket)                    # no-op when world == 1
@@ -290,7 +296,7 @@ def main():
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                     config=dict(workload=desc, batch_per_gpu=batch, global_batch=batch * world,
-                                levels=[list(s) for s in plan.shapes], parallelism=f"dp{world}",
+                                levels=[list(s) for s in plan.shapes], parallelism=f"dp{world}", backend=(args.backend if world > 1 else None),
                                 launch="eager" if args.no_graph else ("hipGraph replay, 1 graph/step" if world == 1 else "hipGraph replay, 2 graphs/step (split at the gradient-exchange join)"),
                                 grad_exchange=None if world == 1 else f"RCCL all-reduce of one {plan.grad_bucket.numel() * 4} B bucket per step, overlapped with the next step's parameter-free k_pool"),
                     roofline=roofline, step_roofline=step_roof, kernels=kernels, cpu_baseline=cpu,

@@ -7,7 +7,7 @@ import os
 import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmgacbam.so")
+LIB_PATH = os.environ.get("MGACBAM_LIB") or os.path.join(_PKG, "libmgacbam.so")   # MGACBAM_LIB: A/B builds in tuning sweeps
 ABI_VERSION = 5
 MAX_LEVELS = 8
 F32, F16, BF16 = 0, 1, 2

@@ -34,12 +34,12 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, resource_log: str | None = None) -> str:
+def build(force: bool = False, verbose: bool = False, resource_log: str | None = None, defines=(), out: str | None = None) -> str:
     """Compile csrc/*.hip for gfx950 into mga_yolo_amd/libmgacbam.so; returns the library path."""
-    if not force and not is_stale():
+    if not force and not is_stale() and not out:
         return LIB
     cmd = [hipcc_path(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-shared", "-fPIC",
-           "-Wno-pass-failed", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wno-pass-failed", "-o", out or LIB] + list(defines) + [os.path.join(CSRC, s) for s in SOURCES]
     if resource_log:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     if verbose:
@@ -50,7 +50,7 @@ def build(force: bool = False, verbose: bool = False, resource_log: str | None =
             f.write(r.stderr)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

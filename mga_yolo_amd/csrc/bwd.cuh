@@ -288,7 +288,7 @@ __device__ __forceinline__ void bwd_reduce2_body(const BwdArgs& A, const int bid
 #pragma unroll
   for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
 
-  constexpr int PF = 4;                                       // positions per lane per memory round (see k_pool)
+  constexpr int PF = MGACBAM_POOL_PF;                         // positions per lane per memory round (see k_pool)
   for (int i0 = tx; i0 < nv; i0 += TX * PF) {
     float g0[PF][VEC], g1[PF][VEC], xv[PF][CPT][VEC];
     int ci[PF][VEC];

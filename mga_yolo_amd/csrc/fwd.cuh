@@ -17,6 +17,10 @@
 #include "args.cuh"
 #include "common.cuh"
 
+#ifndef MGACBAM_POOL_PF
+#define MGACBAM_POOL_PF 1   // H*W positions per lane per memory round in the sweep kernels (k_pool, k_bwd_reduce2)
+#endif
+
 namespace mgacbam {
 
 // ---------------------------------------------------------------------------------------------
@@ -57,7 +61,7 @@ __device__ __forceinline__ void pool_body(const FwdArgs& A, const int bid, float
 
   // PF positions per lane are requested per round: a lane's sweep is a chain of dependent memory rounds (each ~2.5 us
   // under load), so the kernel cannot finish before rounds x latency -- fewer, fatter rounds (profiles/ notes, membw).
-  constexpr int PF = 4;
+  constexpr int PF = MGACBAM_POOL_PF;
   for (int i0 = tx; i0 < nv; i0 += TX * PF) {
     float m[PF][VEC], xv[PF][CPT][VEC];
     bool ok[PF];

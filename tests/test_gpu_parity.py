@@ -131,10 +131,15 @@ def test_full_size_checksums_vs_reference(F, checksums, name):
 
 
 @pytest.mark.parametrize("shape,mask_kind", [((32, 64, 80, 80), "sparse"), ((32, 128, 40, 40), "randn"), ((32, 256, 20, 20), "sparse"),
-                                             ((4, 192, 40, 40), "mixed"), ((2, 384, 20, 20), "randn"), ((3, 48, 17, 17), "mixed")])
+                                             ((4, 192, 40, 40), "mixed"), ((2, 384, 20, 20), "randn"), ((3, 48, 17, 17), "mixed"),
+                                             ((1, 256, 160, 160), "sparse"), ((2, 512, 40, 40), "randn"), ((1, 768, 20, 20), "mixed"),
+                                             ((5, 64, 24, 40), "mixed"), ((9, 32, 6, 10), "randn"), ((1, 1, 1, 1), "randn"),
+                                             ((2, 3, 2, 3), "randn"), ((1, 16, 1, 37), "sparse"), ((11, 24, 13, 4), "mixed")])
 def test_full_size_vs_oracle_live(F, shape, mask_kind):
     """Same seeded inputs through the oracle (CPU) and the HIP path, element-wise, at config-2 sizes and the odd shapes."""
     B, C, H, W = shape
+    if mask_kind == "mixed" and B < 2:
+        mask_kind = "randn"
     x, mask, gy = synth(B, C, H, W, seed=77, mask_kind=mask_kind)
     p = O.Params.default_init(C, seed=3)
     p.beta.fill_(0.3)
@@ -317,3 +322,22 @@ def test_plan_executor_matches_oracle_with_and_without_projection_planes(F, want
     torch.cuda.synchronize()
     for a, b in zip(ref, list(plan.gx) + [plan.grad_bucket]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("k", [1, 9, 11, 15])
+def test_generic_spatial_kernel_sizes(F, k):
+    """spatial_k other than 3/5/7 takes the run-time-k code paths of the conv prologue, transposed conv and dWsa kernels."""
+    B, C, H, W = 3, 32, 12, 20
+    x, mask, gy = synth(B, C, H, W, seed=k, mask_kind="mixed")
+    p = O.Params.default_init(C, k=k, seed=2)
+    with torch.no_grad():
+        p.wsa.mul_(3.0)
+    y_o, c = O.forward(x, mask, p)
+    g_o = O.backward(gy, x, mask, p, O.Config(), c)
+    d = dict(x=x, mask=mask, gy=gy, params={"cam_mlp.0.weight": p.w1, "cam_mlp.0.bias": p.b1, "cam_mlp.2.weight": p.w2,
+                                            "cam_mlp.2.bias": p.b2, "sam_conv.weight": p.wsa, "beta": p.beta},
+             meta=dict(k=k, use_sigmoid_mask=True, tiny_thr=1e-4, eps=1e-6))
+    y, g = _run_gpu(F, d)
+    assert rel_err(y, y_o) < TOL
+    for name in GRADS:
+        assert rel_err(g[name], g_o[name]) < TOL, name
