@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the bounded CPU-baseline sample")
     ap.add_argument("--kernel-reps", type=int, default=30)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "bf16"], help="element type of x / y / gy / gx (headline = f32)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for rehearsing the multi-rank code path on one GPU)")
     return ap.parse_args()
 
@@ -75,7 +76,7 @@ def relaunch_distributed(args):
     return subprocess.call(cmd)
 
 
-def make_plan(workload, device, seed):
+def make_plan(workload, device, seed, dtype_name="f32"):
     import torch
     from mga_yolo_amd import MaskCBAM
     from mga_yolo_amd.plan import PyramidPlan
@@ -85,7 +86,8 @@ def make_plan(workload, device, seed):
         torch.manual_seed(0)                                   # default init, seed 0
         m = MaskCBAM(C)
         shapes.append((batch, C, H, W)); params.append(m.block_params()); cfgs.append(m.block_config())
-    plan = PyramidPlan(shapes, params, cfgs, dtype=torch.float32, device=device, with_mask=True, want_gmask=True)
+    dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dtype_name]
+    plan = PyramidPlan(shapes, params, cfgs, dtype=dt, device=device, with_mask=True, want_gmask=True)
     g = torch.Generator(device="cpu").manual_seed(seed)
     for l, (B, C, H, W) in enumerate(shapes):                  # SiLU-shaped features, sparse (vessel-like) masks, N(0,1) upstream grads
         plan.x[l].copy_(torch.nn.functional.silu(torch.randn(B, C, H, W, generator=g)))
@@ -198,7 +200,7 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    plan, desc, batch = make_plan(args.workload, device, seed=1234 + rank)
+    plan, desc, batch = make_plan(args.workload, device, seed=1234 + rank, dtype_name=args.dtype)
     exchange = GradExchange(plan.grad_bucket)                    # no-op when world == 1
 
     S = _lib.FWD_STAGES
@@ -259,7 +261,7 @@ def main():
     # ---- per-kernel durations on this GPU, isolated launches on the same stream -------------------------------
     kt = time_kernels(plan, args.kernel_reps)
     E = plan.elements()
-    w = 4
+    w = 4 if args.dtype == "f32" else 2
     kernels = {}
     event_pad = kt.pop("_event_pad_us")
     for name, us in kt.items():
@@ -294,7 +296,7 @@ def main():
     if rank == 0:
         line = dict(metric="images/s (MaskCBAM fwd+bwd step at P3/P4/P5, YOLOv8n 640x640)", value=round(value, 1), unit="images/s",
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
-                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                     config=dict(workload=desc, batch_per_gpu=batch, global_batch=batch * world,
                                 levels=[list(s) for s in plan.shapes], parallelism=f"dp{world}", backend=(args.backend if world > 1 else None),
                                 launch="eager" if args.no_graph else ("hipGraph replay, 1 graph/step" if world == 1 else "hipGraph replay, 2 graphs/step (split at the gradient-exchange join)"),

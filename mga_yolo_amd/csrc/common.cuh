@@ -27,7 +27,7 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ __half from_f32<__half>(float v) { return __float2half_rn(v); }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return __float2bfloat16(v); }
 
-template <typename T, int VEC> struct alignas(sizeof(T) * VEC) Pack { T v[VEC]; };
+template <typename T, int VEC> struct alignas(sizeof(T) * VEC < 16 ? sizeof(T) * VEC : 16) Pack { T v[VEC]; };
 
 // one VEC-wide (4 x fp32 = 16 B, 4 x half = 8 B) coalesced load / store per lane
 template <typename T, int VEC>

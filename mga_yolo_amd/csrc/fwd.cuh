@@ -449,8 +449,9 @@ __device__ __forceinline__ void apply_body(const FwdArgs& A, const int bid, floa
   const float* pl = A.c.planes + static_cast<size_t>(b) * 3 * g.HW;
   stage_window<12>(planes, 3, PH, PW, r0 - pad, -pad, g, [&](int p) { return pl + static_cast<size_t>(p) * g.HW; });
   __syncthreads();
-  if (tid < TP && p0 + tid < g.HW) {
-    const int p = p0 + tid;
+  for (int tp = tid; tp < TP; tp += kBlock) {                  // one pixel per thread (TP <= 512)
+    if (p0 + tp >= g.HW) break;
+    const int p = p0 + tp;
     const int py = p / g.W, px = p - py * g.W;
     const float* origin = planes + (py - r0) * PW + px;         // tap (i,j) of plane q: origin[q*PH*PW + i*PW + j]
     float acc = 0.f;
@@ -475,7 +476,7 @@ __device__ __forceinline__ void apply_body(const FwdArgs& A, const int bid, floa
         }
     }
     const float sa = sigmoidf_(acc);                            // masked_cbam.py:147
-    s_sa[tid] = sa;
+    s_sa[tp] = sa;
     A.c.sa[static_cast<size_t>(b) * g.HW + p] = sa;
   }
   __syncthreads();

@@ -95,10 +95,17 @@ static int env_int(const char* name, int dflt) {
 }
 static bool is_pow2_in(int v, int lo, int hi) { return v >= lo && v <= hi && (v & (v - 1)) == 0; }
 
-static int vec_of(int H, int W) { return ((static_cast<long long>(H) * W) % 4 == 0) ? 4 : 1; }
+// elements per lane per access: 4 (16 B fp32, 8 B fp16/bf16) when the row length allows, else scalar.  8-element (16 B)
+// half vectors exist (MGACBAM_HALF_VEC=8) but halve the tile count, which starves the small levels (P5: 128 workgroups;
+// k_chan 19 -> 33 us at YOLOv8n sizes), so they are opt-in for large feature maps only
+static int vec_of(int H, int W, int dtype = MGACBAM_F32) {
+  const long long hw = static_cast<long long>(H) * W;
+  if (dtype != MGACBAM_F32 && hw % 8 == 0 && env_int("MGACBAM_HALF_VEC", 4) == 8) return 8;
+  return hw % 4 == 0 ? 4 : 1;
+}
 
-static Tune choose_tune(int B, int C, int H, int W, int k) {
-  const int HW = H * W, VEC = vec_of(H, W), nv = HW / VEC;
+static Tune choose_tune(int B, int C, int H, int W, int k, int dtype = MGACBAM_F32) {
+  const int HW = H * W, VEC = vec_of(H, W, dtype), nv = HW / VEC;
   Tune t;
   // rows of TX lanes sweep H*W: aim for >= 4 sweeps per lane, then shrink channels/row until the grid fills the chip
   int tx = pow2_floor(nv / 4 > 0 ? nv / 4 : 1);
@@ -152,8 +159,8 @@ static int wsa_tiles(const Tune& t, int H, int W) {
   const int TW = t.conv_twq * 4;
   return ((W + TW - 1) / TW) * ((H + t.wsa_th - 1) / t.wsa_th);
 }
-static int chan_tiles(const Tune& t, int H, int W) {
-  const int nv = H * W / vec_of(H, W);
+static int chan_tiles(const Tune& t, int H, int W, int vec) {
+  const int nv = H * W / vec;
   return (nv + t.chan_tx - 1) / t.chan_tx;
 }
 
@@ -161,7 +168,7 @@ struct ScratchLayout { size_t A_part, Q_part, gpre, gplanes, gwsa_part, gz, gbq,
 static ScratchLayout scratch_layout(int B, int C, int H, int W, int hidden, int k) {
   const Tune t = choose_tune(B, C, H, W, k);
   const size_t HW = static_cast<size_t>(H) * W, BC = static_cast<size_t>(B) * C;
-  const size_t nt = chan_tiles(t, H, W), nconv = static_cast<size_t>(B) * wsa_tiles(t, H, W);
+  const size_t nt = chan_tiles(t, H, W, vec_of(H, W)), nconv = static_cast<size_t>(B) * wsa_tiles(t, H, W);
   ScratchLayout L;
   size_t o = 0;
   auto take = [&](size_t n_elems) { size_t at = o; o = align16(o + n_elems * 4); return at; };
@@ -206,8 +213,8 @@ static bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintp
 #define DISPATCH_T_VEC(dtype, VECV, CALL)                                                         \
   do {                                                                                            \
     if ((dtype) == MGACBAM_F32) { if ((VECV) == 4) { CALL(float, 4); } else { CALL(float, 1); } }  \
-    else if ((dtype) == MGACBAM_F16) { if ((VECV) == 4) { CALL(__half, 4); } else { CALL(__half, 1); } } \
-    else { if ((VECV) == 4) { CALL(bf16_t, 4); } else { CALL(bf16_t, 1); } }          \
+    else if ((dtype) == MGACBAM_F16) { if ((VECV) == 8) { CALL(__half, 8); } else if ((VECV) == 4) { CALL(__half, 4); } else { CALL(__half, 1); } } \
+    else { if ((VECV) == 8) { CALL(bf16_t, 8); } else if ((VECV) == 4) { CALL(bf16_t, 4); } else { CALL(bf16_t, 1); } }          \
   } while (0)
 
 #define DISPATCH_CPT(CPTV, CALL2)                                              \
@@ -285,15 +292,15 @@ static int forward_args(const mgacbam_fwd_level_t& L, FwdArgs& A, Sig& sig) {
   if (int e = check_params(L.p)) return e;
   if (int e = check_shape(L.B, L.C, L.H, L.W, L.p.hidden, L.p.k)) return e;
   if (L.dtype < MGACBAM_F32 || L.dtype > MGACBAM_BF16) return fail(MGACBAM_E_DTYPE, "forward: dtype %d", L.dtype);
-  const int VEC = vec_of(L.H, L.W);
+  const int VEC = vec_of(L.H, L.W, L.dtype);
   const size_t need = VEC * elem_size(L.dtype);
-  if (!aligned_to(L.x, need) || !aligned_to(L.y, need) || !aligned_to(L.ctx, 16) || (L.mask && !aligned_to(L.mask, VEC * 4)))
+  if (!aligned_to(L.x, need) || !aligned_to(L.y, need) || !aligned_to(L.ctx, 16) || (L.mask && !aligned_to(L.mask, 16)))
     return fail(MGACBAM_E_ALIGN, "forward: x/y must be %zu-byte aligned, ctx 16-byte, mask %d-byte", need, VEC * 4);
   A.x = L.x; A.mask = L.mask; A.y = L.y;
   A.c = ctx_ptrs(L.ctx, L.B, L.C, L.H, L.W, L.p.hidden);
   A.p = make_params(L.p);
   A.g = make_geo(L.B, L.C, L.H, L.W, L.p);
-  A.t = choose_tune(L.B, L.C, L.H, L.W, L.p.k);
+  A.t = choose_tune(L.B, L.C, L.H, L.W, L.p.k, L.dtype);
   const int proj = (L.flags & MGACBAM_FWD_SAVE_PROJ) && L.mask != nullptr;
   A.g.proj_h = (proj && L.p.hidden <= MGACBAM_PROJ_MAX_HIDDEN) ? L.p.hidden : 0;
   sig = Sig{L.dtype, VEC, L.mask != nullptr, L.p.k, 0, proj};
@@ -319,7 +326,7 @@ static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStre
   if (stages & MGACBAM_FWD_CHAN) {  // 2. shared MLP + channel gate (prologue), channel max / mean planes
     size_t smem = 0;
     for (int l = 0; l < n; ++l) smem = std::max(smem, chan_smem(lv[l].g, sig.vec, sig.proj));
-    const int grid = fill([&](const FwdArgs& a) { return xcd_grid(a.g.B, chan_tiles(a.t, a.g.H, a.g.W)); });
+    const int grid = fill([&](const FwdArgs& a) { return xcd_grid(a.g.B, chan_tiles(a.t, a.g.H, a.g.W, sig.vec)); });
 #define CALL_CHAN(Tt, Vv) if (sig.proj) LAUNCH((k_chan<Tt, Vv, true>), grid, smem, st, G); else LAUNCH((k_chan<Tt, Vv, false>), grid, smem, st, G)
     DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_CHAN);
 #undef CALL_CHAN
@@ -328,7 +335,7 @@ static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStre
   if (stages & MGACBAM_FWD_APPLY) {  // 3. k x k conv + spatial gate (prologue), both gates + alpha residual
     size_t smem = 0;
     for (int l = 0; l < n; ++l) smem = std::max(smem, apply_smem(lv[l].g, lv[l].t, sig.vec));
-    const int grid = fill([&](const FwdArgs& a) { return xcd_grid(a.g.B, chan_tiles(a.t, a.g.H, a.g.W)); });
+    const int grid = fill([&](const FwdArgs& a) { return xcd_grid(a.g.B, chan_tiles(a.t, a.g.H, a.g.W, sig.vec)); });
 #define CALL_APPLY(Tt, Vv)                                                    \
     switch (sig.k) {                                                          \
       case 3: LAUNCH((k_apply<Tt, Vv, 3>), grid, smem, st, G); break;         \
@@ -389,17 +396,17 @@ static int backward_args(const mgacbam_bwd_level_t& L, BwdArgs& A, Sig& sig) {
   if (int e = check_params(L.p)) return e;
   if (int e = check_shape(L.B, L.C, L.H, L.W, L.p.hidden, L.p.k)) return e;
   if (L.dtype < MGACBAM_F32 || L.dtype > MGACBAM_BF16) return fail(MGACBAM_E_DTYPE, "backward: dtype %d", L.dtype);
-  const int VEC = vec_of(L.H, L.W);
+  const int VEC = vec_of(L.H, L.W, L.dtype);
   const size_t need = VEC * elem_size(L.dtype);
   if (!aligned_to(L.x, need) || !aligned_to(L.gy, need) || !aligned_to(L.gx, need) || !aligned_to(L.ctx, 16) ||
-      !aligned_to(L.scratch, 16) || (L.gmask && !aligned_to(L.gmask, VEC * 4)))
+      !aligned_to(L.scratch, 16) || (L.gmask && !aligned_to(L.gmask, 16)))
     return fail(MGACBAM_E_ALIGN, "backward: x/gy/gx must be %zu-byte aligned, ctx/scratch 16-byte", need);
   A.x = L.x; A.mask = L.mask; A.gy = L.gy; A.gx = L.gx; A.gmask = L.gmask;
   A.gw1 = L.gw1; A.gb1 = L.gb1; A.gw2 = L.gw2; A.gb2 = L.gb2; A.gwsa = L.gwsa; A.gbeta = L.gbeta;
   A.c = ctx_ptrs(const_cast<void*>(L.ctx), L.B, L.C, L.H, L.W, L.p.hidden);
   A.p = make_params(L.p);
   A.g = make_geo(L.B, L.C, L.H, L.W, L.p);
-  A.t = choose_tune(L.B, L.C, L.H, L.W, L.p.k);
+  A.t = choose_tune(L.B, L.C, L.H, L.W, L.p.k, L.dtype);
   const ScratchLayout SL = scratch_layout(L.B, L.C, L.H, L.W, L.p.hidden, L.p.k);
   char* sp = static_cast<char*>(L.scratch);
   A.s.A_part = reinterpret_cast<float*>(sp + SL.A_part); A.s.Q_part = reinterpret_cast<float*>(sp + SL.Q_part);
@@ -409,7 +416,7 @@ static int backward_args(const mgacbam_bwd_level_t& L, BwdArgs& A, Sig& sig) {
   A.s.gh_avg = reinterpret_cast<float*>(sp + SL.gh_avg); A.s.gh_mx = reinterpret_cast<float*>(sp + SL.gh_mx);
   A.s.chan4 = reinterpret_cast<float*>(sp + SL.chan4); A.s.Kb = reinterpret_cast<float*>(sp + SL.Kb);
   A.s.pgh = reinterpret_cast<float*>(sp + SL.pgh);
-  A.nt = chan_tiles(A.t, A.g.H, A.g.W);
+  A.nt = chan_tiles(A.t, A.g.H, A.g.W, VEC);
   A.nconv = A.g.B * conv_tiles(A.t, A.g.H, A.g.W);
   A.nwsa = A.g.B * wsa_tiles(A.t, A.g.H, A.g.W);
   A.npg = params_blocks(A.g);

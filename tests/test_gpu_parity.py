@@ -224,10 +224,11 @@ def test_every_launch_geometry_gives_the_same_answer(F, env, monkeypatch):
                 assert rel_err(g[k], d["out"][k]) < TOL, (name, k)
 
 
+@pytest.mark.parametrize("hw", [(20, 20), (6, 6), (5, 7), (40, 40)])     # 16-byte (8-element), 8-byte and scalar access paths
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
-def test_half_precision_io(F, dtype, tol):
+def test_half_precision_io(F, dtype, tol, hw):
     """fp16 / bf16 features and gradients with fp32 accumulation, against the fp32 oracle on the rounded inputs."""
-    B, C, H, W = 4, 64, 20, 20
+    B, C, (H, W) = 4, 64, hw
     x, mask, gy = synth(B, C, H, W, seed=21)
     x, gy = x.to(dtype).float(), gy.to(dtype).float()
     p = O.Params.default_init(C)
