@@ -242,13 +242,14 @@ struct Sig {
   }
 };
 
-// channels per thread for the row-sweep kernels, uniform over a group: the largest of {4,2,1} that still gives the
-// chip >= 6 workgroups per CU
+// channels per thread for the row-sweep kernels, uniform over a group: 2 when that still gives the chip >= 6 workgroups
+// per CU, else 1 (4 is instantiated and reachable through MGACBAM_POOL_CPT, but measured slower at every benchmark shape:
+// k_pool 80 us vs 91 us at config 4, 22 vs 26 us at config 2)
 template <typename Args>
 static int group_cpt(const Args* lv, int n, bool apply_kernel) {
   const int forced = env_int(apply_kernel ? "MGACBAM_APPLY_CPT" : "MGACBAM_POOL_CPT", 0);
   if (forced == 1 || forced == 2 || forced == 4) return forced;
-  for (int cpt = 4; cpt > 1; cpt /= 2) {
+  for (int cpt = 2; cpt > 1; cpt /= 2) {
     long long blocks = 0;
     for (int l = 0; l < n; ++l) {
       const int tx = apply_kernel ? lv[l].t.apply_tx : lv[l].t.pool_tx;

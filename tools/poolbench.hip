@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <stdio.h>
+#include <stdlib.h>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 template <int CPT, int LEVEL>   // LEVEL 0: x only; 1: + mask load; 2: + sigmoid & sxs; 3: + argmax; 4: + block reduction epilogue
@@ -67,8 +68,9 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ x, const floa
   }
 }
 
-int main() {
-  const int B = 32, C = 64, HW = 6400;
+int main(int argc, char** argv) {
+  const int B = argc > 3 ? atoi(argv[1]) : 32, C = argc > 3 ? atoi(argv[2]) : 64, HW = argc > 3 ? atoi(argv[3]) : 6400;
+  printf("B=%d C=%d HW=%d (%.1f MB)\n", B, C, HW, B * (double)C * HW * 4 / 1e6);
   const size_t n = (size_t)B * C * HW;
   float *x, *m, *o;
   CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&m, (size_t)B * HW * 4)); CK(hipMalloc(&o, (size_t)B * C * 16));
@@ -84,7 +86,7 @@ int main() {
   };
 #define RUN(CPT, LEVEL, TX) run("cpt" #CPT " level" #LEVEL " tx" #TX, [&] { hipLaunchKernelGGL((k<CPT, LEVEL>), dim3(B * C / ((256 / TX) * CPT)), dim3(256), 0, 0, x, m, o, B, C, HW, TX); })
   RUN(2, 0, 256); RUN(2, 1, 256); RUN(2, 2, 256); RUN(2, 3, 256); RUN(2, 4, 256);
-  RUN(1, 0, 256); RUN(1, 4, 256); RUN(4, 0, 256); RUN(4, 4, 256);
+  RUN(1, 0, 256); RUN(1, 4, 256); RUN(4, 0, 256); RUN(4, 1, 256); RUN(4, 2, 256); RUN(4, 3, 256); RUN(4, 4, 256);
   RUN(2, 0, 64); RUN(2, 4, 64); RUN(1, 0, 64); RUN(1, 4, 64); RUN(4, 4, 64);
   RUN(2, 0, 128); RUN(2, 4, 128);
   return 0;
