@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from mga_yolo.nn.modules.masked_cbam import MaskCBAM  # the reference itself
+from mga_yolo.nn.modules.masked_eca import MaskECA    # next row
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 torch.set_num_threads(1)  # deterministic summation order
@@ -132,6 +133,48 @@ BIG = [
 ]
 
 
+ECA_CASES = [
+    # name,          B,  C,   H,  W, module kwargs,                     data kwargs
+    ("eca_base",      2, 64,  20, 20, dict(),                            dict()),
+    ("eca_nomask",    2, 32,  12, 12, dict(),                            dict(mask_kind="none")),
+    ("eca_tiny",      2, 16,  10, 10, dict(),                            dict(mask_kind="tiny")),
+    ("eca_mixed",     3, 32,  10, 10, dict(randomize=11),                dict(mask_kind="mixed")),
+    ("eca_mask3d",    1, 16,   8,  8, dict(randomize=2),                 dict(mask3d=True)),
+    ("eca_odd",       2, 48,  17, 17, dict(randomize=4),                 dict(mask_kind="sparse")),
+    ("eca_c256",      2, 256,  5,  5, dict(randomize=6, beta=0.8),       dict()),
+    ("eca_c1024",     1, 1024, 2,  2, dict(randomize=8, beta=-0.7),      dict()),
+    ("eca_prob",      2, 16,   8,  8, dict(use_sigmoid_mask=False),      dict(mask_kind="prob")),
+    ("eca_c8_nonsq",  2, 8,    9,  7, dict(randomize=3),                 dict()),
+    ("eca_kmin7",     1, 32,   6,  6, dict(k_min=7, randomize=9),        dict()),
+]
+
+
+def build_eca(C, use_sigmoid_mask=True, seed=0, randomize=None, beta=None, k_min=3):
+    torch.manual_seed(seed)
+    m = MaskECA(C, use_sigmoid_mask=use_sigmoid_mask, k_min=k_min)
+    if randomize is not None:
+        g = torch.Generator().manual_seed(randomize)
+        with torch.no_grad():
+            for p_ in m.parameters():
+                p_.add_(0.5 * torch.randn(p_.shape, generator=g))
+    if beta is not None:
+        with torch.no_grad():
+            m.beta.fill_(beta)
+    return m
+
+
+def run_eca(m, x, mask, gy):
+    x = x.clone().requires_grad_(True)
+    mk = None if mask is None else mask.clone().requires_grad_(True)
+    m.zero_grad()
+    y = m(x if mk is None else [x, mk])
+    y.backward(gy)
+    out = dict(y=y.detach(), gx=x.grad, gw=m.conv1d.weight.grad.detach().clone(), gbeta=m.beta.grad.detach().clone())
+    if mk is not None:
+        out["gmask"] = mk.grad
+    return out, {k_: v.detach().clone() for k_, v in m.state_dict().items()}
+
+
 def checksum(tn):
     t = tn.double().reshape(-1)
     n = t.numel()
@@ -159,6 +202,24 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"case_{name}.npz"), **arrays)
         index[name] = dict(shape=[B, C, H, W], **meta, ysum=float(out["y"].double().sum()))
         print(f"case {name:16s} y.sum={index[name]['ysum']:.6f}")
+
+    for name, B, C, H, W, mk, dk in ECA_CASES:
+        m = build_eca(C, **mk)
+        x, mask, gy = data(B, C, H, W, **dk)
+        out, sd = run_eca(m, x, mask, gy)
+        arrays = dict(x=x.numpy(), gy=gy.numpy())
+        if mask is not None:
+            arrays["mask"] = mask.numpy()
+        for k_, v in sd.items():
+            arrays["param." + k_] = v.numpy()
+        for k_, v in out.items():
+            arrays["out." + k_] = v.numpy()
+        meta = dict(k=int(m.conv1d.weight.shape[-1]), use_sigmoid_mask=bool(m.cfg.use_sigmoid_mask),
+                    tiny_thr=m.cfg.tiny_mask_threshold, eps=m.cfg.eps, k_min=mk.get("k_min", 3))
+        arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **arrays)
+        index[name] = dict(shape=[B, C, H, W], **meta, ysum=float(out["y"].double().sum()))
+        print(f"eca  {name:16s} k={meta['k']} y.sum={index[name]['ysum']:.6f}")
 
     sums = {}
     for name, B, C, H, W, mkind, recipe in BIG:
