@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MGACBAM_ABI_VERSION 5
+#define MGACBAM_ABI_VERSION 6
 #define MGACBAM_MAX_LEVELS 8          /* P3/P4/P5 need 3 */
 
 enum { MGACBAM_F32 = 0, MGACBAM_F16 = 1, MGACBAM_BF16 = 2 };
@@ -168,6 +168,50 @@ int mgacbam_backward_stages(const mgacbam_bwd_level_t* levels, int n_levels, int
  * (F.interpolate(mode="nearest")).  Bit-exact with the reference by construction (pure gather). */
 int mgacbam_resize_nearest(const float* src, float* dst, int n_planes, int in_h, int in_w, int out_h, int out_w,
                            void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * MaskECA -- the second mask-guided attention block of the reference (mga_yolo/nn/modules/masked_eca.py:68-196), behind the
+ * same boundary: masked average pooling (GAP fallback for tiny masks) -> k-tap conv1d over the channel axis -> sigmoid ->
+ * y = x * (1 + softplus(beta) * (w - 0.5)).  Same conventions as above (caller-owned buffers, explicit stream, no sync).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct mgacbam_eca_params {
+  const float* w;            /* conv1d.weight (1,1,k) fp32                  masked_eca.py:124 */
+  const float* beta;         /* beta ()                                     masked_eca.py:127 */
+  int32_t k;                 /* odd, 1..15 (eca_kernel_size, :44-54)        */
+  int32_t use_sigmoid_mask;  /* :63  */
+  float tiny_thr;            /* :64  */
+  float eps;                 /* :65  */
+} mgacbam_eca_params_t;
+
+typedef struct mgacbam_eca_fwd_level {
+  const void* x;             /* (B,C,H,W) */
+  const float* mask;         /* (B,1,H,W) fp32 or NULL */
+  void* y;
+  void* ctx;                 /* mgacbam_eca_ctx_bytes() */
+  mgacbam_eca_params_t p;
+  int32_t B, C, H, W;
+  int32_t dtype;
+} mgacbam_eca_fwd_level_t;
+
+typedef struct mgacbam_eca_bwd_level {
+  const void* x;
+  const float* mask;
+  const void* gy;
+  const void* ctx;
+  void* scratch;             /* mgacbam_eca_scratch_bytes() */
+  void* gx;
+  float* gmask;              /* or NULL */
+  float* gw;                 /* (1,1,k), overwritten */
+  float* gbeta;
+  mgacbam_eca_params_t p;
+  int32_t B, C, H, W;
+  int32_t dtype;
+} mgacbam_eca_bwd_level_t;
+
+size_t mgacbam_eca_ctx_bytes(int B, int C, int H, int W);
+size_t mgacbam_eca_scratch_bytes(int B, int C, int H, int W);
+int mgacbam_eca_forward(const mgacbam_eca_fwd_level_t* levels, int n_levels, void* stream);    /* 2 launches */
+int mgacbam_eca_backward(const mgacbam_eca_bwd_level_t* levels, int n_levels, void* stream);   /* 2 launches */
 
 #ifdef __cplusplus
 }

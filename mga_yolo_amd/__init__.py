@@ -7,9 +7,10 @@
 Layout: ``csrc/`` hand-written HIP kernels + the C ABI of ``include/mgacbam.h``; ``_lib`` ctypes binding (no fallback);
 ``functional`` autograd entry points; ``module`` the nn.Module mirror; ``dp`` data-parallel gradient exchange (RCCL).
 """
-from .functional import BlockConfig, mask_cbam, mask_cbam_pyramid, resize_nearest  # noqa: F401
+from .functional import BlockConfig, EcaConfig, mask_cbam, mask_cbam_pyramid, mask_eca, mask_eca_pyramid, resize_nearest  # noqa: F401
 from .install import install  # noqa: F401
-from .module import MaskCBAM, ProbMaskGater  # noqa: F401
+from .module import MaskCBAM, MaskECA, ProbMaskGater  # noqa: F401
 
-__all__ = ["MaskCBAM", "ProbMaskGater", "BlockConfig", "mask_cbam", "mask_cbam_pyramid", "resize_nearest", "install"]
+__all__ = ["MaskCBAM", "MaskECA", "ProbMaskGater", "BlockConfig", "EcaConfig", "mask_cbam", "mask_cbam_pyramid", "mask_eca",
+           "mask_eca_pyramid", "resize_nearest", "install"]
 __version__ = "0.1.0"

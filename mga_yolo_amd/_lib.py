@@ -8,7 +8,7 @@ import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGACBAM_LIB") or os.path.join(_PKG, "libmgacbam.so")   # MGACBAM_LIB: A/B builds in tuning sweeps
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_LEVELS = 8
 F32, F16, BF16 = 0, 1, 2
 # stage bit masks (include/mgacbam.h)
@@ -43,6 +43,22 @@ class BwdLevel(C.Structure):                     # mgacbam_bwd_level_t
                 ("dtype", C.c_int32), ("flags", C.c_int32)]
 
 
+class EcaParams(C.Structure):                    # mgacbam_eca_params_t
+    _fields_ = [("w", C.c_void_p), ("beta", C.c_void_p), ("k", C.c_int32), ("use_sigmoid_mask", C.c_int32),
+                ("tiny_thr", C.c_float), ("eps", C.c_float)]
+
+
+class EcaFwdLevel(C.Structure):                  # mgacbam_eca_fwd_level_t
+    _fields_ = [("x", C.c_void_p), ("mask", C.c_void_p), ("y", C.c_void_p), ("ctx", C.c_void_p), ("p", EcaParams),
+                ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dtype", C.c_int32)]
+
+
+class EcaBwdLevel(C.Structure):                  # mgacbam_eca_bwd_level_t
+    _fields_ = [("x", C.c_void_p), ("mask", C.c_void_p), ("gy", C.c_void_p), ("ctx", C.c_void_p), ("scratch", C.c_void_p),
+                ("gx", C.c_void_p), ("gmask", C.c_void_p), ("gw", C.c_void_p), ("gbeta", C.c_void_p), ("p", EcaParams),
+                ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dtype", C.c_int32)]
+
+
 CTX_FIELDS = ("S", "use", "den", "avg", "mx", "mavg", "valid", "amax", "h_avg", "h_mx", "ca", "planes", "cidx", "sa", "proj", "total")
 
 
@@ -63,6 +79,10 @@ SYMBOLS = {
     "mgacbam_forward_stages": (C.c_int, [C.POINTER(FwdLevel), C.c_int, C.c_int, C.c_void_p]),
     "mgacbam_backward_stages": (C.c_int, [C.POINTER(BwdLevel), C.c_int, C.c_int, C.c_void_p]),
     "mgacbam_resize_nearest": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
+    "mgacbam_eca_ctx_bytes": (C.c_size_t, [C.c_int] * 4),
+    "mgacbam_eca_scratch_bytes": (C.c_size_t, [C.c_int] * 4),
+    "mgacbam_eca_forward": (C.c_int, [C.POINTER(EcaFwdLevel), C.c_int, C.c_void_p]),
+    "mgacbam_eca_backward": (C.c_int, [C.POINTER(EcaBwdLevel), C.c_int, C.c_void_p]),
 }
 
 _lib = None

@@ -202,6 +202,113 @@ def ctx_views(cbuf: torch.Tensor, B, Cc, H, W, hidden) -> dict:
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------
+# MaskECA
+# ---------------------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class EcaConfig:
+    """Non-tensor state of a MaskECA block (masked_eca.py:57-65)."""
+    k: int
+    use_sigmoid_mask: bool = True
+    tiny_thr: float = 1e-4
+    eps: float = 1e-6
+
+
+class _EcaFn(torch.autograd.Function):
+    """n independent levels; flat inputs = n x (x, mask|None, conv1d.weight, beta)."""
+
+    @staticmethod
+    def forward(ctx, cfgs: Tuple[EcaConfig, ...], *flat):
+        n = len(cfgs)
+        assert len(flat) == 4 * n and 1 <= n <= _lib.MAX_LEVELS
+        lib = _lib.load()
+        levels = (_lib.EcaFwdLevel * n)()
+        keep, outs, meta = [], [], []
+        dev = flat[0].device
+        for l in range(n):
+            x, mask, w, beta = flat[4 * l:4 * l + 4]
+            cfg = cfgs[l]
+            if not x.is_cuda or x.device != dev:
+                raise RuntimeError("mask_eca: all features must live on the same GPU")
+            if x.dim() != 4:
+                raise AssertionError("feature must be (B,C,H,W)")                    # masked_eca.py:174
+            if x.dtype not in _DTYPES:
+                raise TypeError(f"unsupported feature dtype {x.dtype}")
+            B, Cc, H, W = x.shape
+            if mask is not None:
+                m4 = mask.unsqueeze(1) if mask.dim() == 3 else mask
+                if tuple(m4.shape) != (B, 1, H, W):
+                    raise RuntimeError(f"mask shape {tuple(mask.shape)} does not match feature (B,1,H,W)=({B},1,{H},{W})")
+            if tuple(w.shape) != (1, 1, cfg.k) or beta.dim() != 0:
+                raise ValueError(f"MaskECA parameters: expected conv1d.weight (1,1,{cfg.k}) and scalar beta")
+            xc = _aligned(x.detach())
+            m32 = None if mask is None else _aligned(mask.detach().reshape(B, 1, H, W).float())
+            wc, bc = _aligned(w.detach().float()), _aligned(beta.detach().float())
+            y = torch.empty_like(xc)
+            cbuf = torch.empty(lib.mgacbam_eca_ctx_bytes(B, Cc, H, W), dtype=torch.uint8, device=dev)
+            L = levels[l]
+            L.x, L.mask, L.y, L.ctx = xc.data_ptr(), (None if m32 is None else m32.data_ptr()), y.data_ptr(), cbuf.data_ptr()
+            L.p = _lib.EcaParams(wc.data_ptr(), bc.data_ptr(), cfg.k, int(cfg.use_sigmoid_mask), cfg.tiny_thr, cfg.eps)
+            L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[x.dtype]
+            keep += [xc, m32, cbuf, wc, bc]
+            outs.append(y)
+            meta.append(None if mask is None else (mask.dtype, tuple(mask.shape)))
+        with torch.cuda.device(dev):
+            _lib.check(lib.mgacbam_eca_forward(levels, n, torch.cuda.current_stream(dev).cuda_stream), "mgacbam_eca_forward")
+        ctx.save_for_backward(*keep)
+        ctx.cfgs, ctx.meta = cfgs, meta
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        cfgs, n = ctx.cfgs, len(ctx.cfgs)
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        levels = (_lib.EcaBwdLevel * n)()
+        grads: List[Optional[torch.Tensor]] = [None]
+        hold = []
+        dev = saved[0].device
+        for l in range(n):
+            xc, m32, cbuf, wc, bc = saved[5 * l:5 * l + 5]
+            cfg = cfgs[l]
+            B, Cc, H, W = xc.shape
+            gy = gys[l]
+            gy = torch.zeros_like(xc) if gy is None else _aligned(gy.to(xc.dtype))
+            want_gmask = m32 is not None and ctx.needs_input_grad[1 + 4 * l + 1]
+            gx = torch.empty_like(xc)
+            gmask = torch.empty_like(m32) if want_gmask else None
+            gw, gb = torch.empty_like(wc), torch.empty_like(bc)
+            scratch = torch.empty(lib.mgacbam_eca_scratch_bytes(B, Cc, H, W), dtype=torch.uint8, device=dev)
+            L = levels[l]
+            L.x, L.mask, L.gy, L.ctx, L.scratch = (xc.data_ptr(), None if m32 is None else m32.data_ptr(), gy.data_ptr(),
+                                                   cbuf.data_ptr(), scratch.data_ptr())
+            L.gx, L.gmask, L.gw, L.gbeta = gx.data_ptr(), (None if gmask is None else gmask.data_ptr()), gw.data_ptr(), gb.data_ptr()
+            L.p = _lib.EcaParams(wc.data_ptr(), bc.data_ptr(), cfg.k, int(cfg.use_sigmoid_mask), cfg.tiny_thr, cfg.eps)
+            L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[xc.dtype]
+            hold += [gy, scratch]
+            if gmask is not None:
+                mdtype, mshape = ctx.meta[l]
+                gmask = gmask.reshape(mshape).to(mdtype)
+            grads += [gx, gmask, gw, gb]
+        with torch.cuda.device(dev):
+            _lib.check(lib.mgacbam_eca_backward(levels, n, torch.cuda.current_stream(dev).cuda_stream), "mgacbam_eca_backward")
+        del hold
+        return tuple(grads)
+
+
+def mask_eca(x: torch.Tensor, mask: Optional[torch.Tensor], w: torch.Tensor, beta: torch.Tensor, cfg: EcaConfig) -> torch.Tensor:
+    """y = x * (1 + softplus(beta) * (sigmoid(conv1d(masked_avg(x, mask))) - 0.5)) for a device tensor (masked_eca.py:167-196)."""
+    return _EcaFn.apply((cfg,), x, mask, w, beta)[0]
+
+
+def mask_eca_pyramid(levels: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor, torch.Tensor, EcaConfig]]):
+    cfgs, flat = [], []
+    for x, mask, w, beta, cfg in levels:
+        cfgs.append(cfg)
+        flat += [x, mask, w, beta]
+    return _EcaFn.apply(tuple(cfgs), *flat)
+
+
 def resize_nearest(src: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
     """F.interpolate(src, (out_h,out_w), mode='nearest') for fp32 (...,H,W) device tensors: the integer index path of
     mga_yolo/nn/losses/segmentation.py:103-110, bit-exact (pure gather)."""

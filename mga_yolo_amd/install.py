@@ -12,10 +12,11 @@ import importlib
 import sys
 from typing import List
 
-from .module import MaskCBAM
+from .module import MaskCBAM, MaskECA
 
 _TARGETS = ("ultralytics.nn.tasks", "ultralytics.nn", "ultralytics.nn.modules",
-            "mga_yolo.nn.modules.masked_cbam", "mga_yolo.nn.modules", "mga_yolo.nn")
+            "mga_yolo.nn.modules.masked_cbam", "mga_yolo.nn.modules.masked_eca", "mga_yolo.nn.modules", "mga_yolo.nn")
+_CLASSES = {"MaskCBAM": MaskCBAM, "MaskECA": MaskECA}      # parse_model treats both through the same branch (U/nn/tasks.py:1733)
 
 
 def install(strict: bool = False) -> List[str]:
@@ -29,8 +30,12 @@ def install(strict: bool = False) -> List[str]:
                 mod = importlib.import_module(name)
             except Exception:
                 continue
-        if hasattr(mod, "MaskCBAM") or name == "ultralytics.nn.tasks":
-            setattr(mod, "MaskCBAM", MaskCBAM)
+        hit = False
+        for cls_name, cls in _CLASSES.items():
+            if hasattr(mod, cls_name) or name == "ultralytics.nn.tasks":
+                setattr(mod, cls_name, cls)
+                hit = True
+        if hit:
             patched.append(name)
     if strict and "ultralytics.nn.tasks" not in patched:
         raise RuntimeError("ultralytics.nn.tasks is not importable: nothing to install into")

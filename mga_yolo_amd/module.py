@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .functional import BlockConfig, mask_cbam
+from .functional import BlockConfig, EcaConfig, mask_cbam, mask_eca
 
 _GATER_MODES = ("deterministic", "gumbel", "hard_st", "bernoulli_detach")
 
@@ -168,3 +168,91 @@ def _host_forward(x: torch.Tensor, mask: Optional[torch.Tensor], params, cfg: Bl
     planes = torch.cat([u.max(dim=1, keepdim=True)[0], u.mean(dim=1, keepdim=True), plane], dim=1)
     sa = torch.sigmoid(F.conv2d(planes, wsa.to(x.dtype), padding=cfg.k // 2))
     return x + F.softplus(beta).to(x.dtype) * (u * sa - x)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# MaskECA: mirror of mga_yolo/nn/modules/masked_eca.py:68-196
+# ---------------------------------------------------------------------------------------------------------
+def eca_kernel_size(channels: int, gamma: float = 2.0, b: float = 1.0, k_min: int = 3, k_max: int = 15) -> int:
+    """Adaptive odd 1-D kernel size from the channel count (masked_eca.py:44-54)."""
+    if channels <= 0:
+        return k_min
+    k = int(abs((channels.bit_length() - 1) / gamma + b))
+    k = max(k_min, min(k, k_max))
+    return k if k % 2 == 1 else k + 1
+
+
+class _EcaCfg:
+    """Attribute bag with the reference's ``cfg`` field names (masked_eca.py:57-65)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class MaskECA(nn.Module):
+    """Mask-guided Efficient Channel Attention: masked average pooling (GAP fallback for tiny masks) -> conv1d over the
+    channel axis -> sigmoid -> ``x * (1 + softplus(beta) * (w - 0.5))``.  Same constructor, parameter names
+    (``conv1d.weight`` (1,1,k), ``beta``), ``alpha`` / ``scale_name`` / ``cfg`` attributes and ``[feat, mask]`` input as the
+    reference class; device tensors run the HIP kernels (2 launches forward, 2 backward), host tensors plain PyTorch."""
+
+    def __init__(self, channels: int, gamma: float = 2.0, b: float = 1.0, k_min: int = 3, k_max: int = 15,
+                 use_sigmoid_mask: bool = True, tiny_mask_threshold: float = 1e-4, eps: float = 1e-6) -> None:
+        super().__init__()
+        self.cfg = _EcaCfg(channels=channels, gamma=gamma, b=b, k_min=k_min, k_max=k_max, use_sigmoid_mask=use_sigmoid_mask,
+                           tiny_mask_threshold=tiny_mask_threshold, eps=eps)
+        k = eca_kernel_size(channels, gamma=gamma, b=b, k_min=k_min, k_max=k_max)
+        self.conv1d = nn.Conv1d(1, 1, kernel_size=k, padding=k // 2, bias=False)
+        self.beta = nn.Parameter(torch.tensor(0.0, dtype=torch.float32))
+        self.scale_name = {256: "P3", 512: "P4", 1024: "P5"}.get(channels, f"C{channels}")
+
+    @property
+    def alpha(self) -> torch.Tensor:
+        return F.softplus(self.beta)
+
+    def _maybe_rebuild_conv(self, channels: int) -> None:      # masked_eca.py:123-137
+        if channels == self.cfg.channels:
+            return
+        k = eca_kernel_size(channels, gamma=self.cfg.gamma, b=self.cfg.b, k_min=self.cfg.k_min, k_max=self.cfg.k_max)
+        wt = self.conv1d.weight
+        self.conv1d = nn.Conv1d(1, 1, kernel_size=k, padding=k // 2, bias=False).to(device=wt.device, dtype=wt.dtype)
+        self.cfg.channels = channels
+
+    def eca_config(self) -> EcaConfig:
+        return EcaConfig(k=int(self.conv1d.weight.shape[-1]), use_sigmoid_mask=bool(self.cfg.use_sigmoid_mask),
+                         tiny_thr=float(self.cfg.tiny_mask_threshold), eps=float(self.cfg.eps))
+
+    def forward(self, x: Union[torch.Tensor, Sequence[torch.Tensor]]) -> torch.Tensor:
+        if isinstance(x, (list, tuple)):
+            assert len(x) == 2, "MaskECA expects [feature, mask] as inputs"
+            feat, mask = x
+        else:
+            feat, mask = x, None
+        assert isinstance(feat, torch.Tensor) and feat.dim() == 4, "feature must be (B,C,H,W)"
+        self._maybe_rebuild_conv(feat.shape[1])
+        if feat.is_cuda:
+            return mask_eca(feat, mask, self.conv1d.weight, self.beta, self.eca_config())
+        return _eca_host_forward(feat, mask, self.conv1d.weight, self.beta, self.eca_config())
+
+    def extra_repr(self) -> str:
+        c = self.cfg
+        return (f"C={c.channels}, gamma={c.gamma}, b={c.b}, k_min={c.k_min}, k_max={c.k_max}, sigmoid_mask={c.use_sigmoid_mask}, "
+                f"tiny_thr={c.tiny_mask_threshold}, alpha={float(self.alpha.detach())}, scale='{self.scale_name}'")
+
+
+def _eca_host_forward(x, mask, w, beta, cfg: EcaConfig) -> torch.Tensor:
+    """Plain-PyTorch statement for HOST tensors (build-time stride probe, device='cpu')."""
+    B, Cc, H, W = x.shape
+    gap = x.flatten(2).mean(dim=2)
+    if mask is None:
+        v = gap
+    else:
+        m = mask.unsqueeze(1) if mask.dim() == 3 else mask
+        if tuple(m.shape) != (B, 1, H, W):
+            raise RuntimeError(f"mask shape {tuple(mask.shape)} does not match feature (B,1,H,W)=({B},1,{H},{W})")
+        s = (m.sigmoid() if cfg.use_sigmoid_mask else m).to(x.dtype).flatten(2)     # (B,1,N)
+        total = s.sum(dim=2)
+        valid = (total / (H * W) >= cfg.tiny_thr).to(x.dtype)
+        masked = (x.flatten(2) * s).sum(dim=2) / total.clamp_min(cfg.eps)
+        v = masked * valid + gap * (1.0 - valid)
+    gate = torch.sigmoid(F.conv1d(v.unsqueeze(1).to(w.dtype), w, padding=cfg.k // 2).squeeze(1)).view(B, Cc, 1, 1)
+    return x * (1.0 + F.softplus(beta).to(gate.dtype) * (gate - 0.5)).to(x.dtype)
