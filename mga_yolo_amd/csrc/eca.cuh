@@ -221,38 +221,34 @@ __global__ __launch_bounds__(kBlock) void k_eca_reduce(const Group<EcaBwdArgs> G
   }
 }
 
-// dW1d[t] = sum_{b,c} gy1[b,c] * avg[b, c+t-pad] ; dbeta = sigmoid(beta) * sum_{b,c} gg*(w-0.5)   (one workgroup, fixed order)
-__device__ __forceinline__ void eca_params_body(const EcaBwdArgs& A, float* red) {
+// parameter-gradient role workgroups, one per output so each is a short reduction (a single workgroup doing all of them was
+// the tail of the launch: 79 us):  r < k: dW1d[r] = sum_{b,c} gy1[b,c] * avg[b, c+r-pad]   r == 15: dbeta = sigmoid(beta) *
+// sum_{b,c} gg*(w-0.5).  Fixed summation order => reproducible.
+constexpr int kEcaRoles = 16;
+__device__ __forceinline__ void eca_params_body(const EcaBwdArgs& A, const int r, float* red) {
   const Geo& g = A.g;
   const int tid = threadIdx.x, k = g.k, pad = k / 2, BC = g.B * g.C;
+  if (r >= k && r != kEcaRoles - 1) return;
   const float a = softplusf_(*A.beta);
-  float acc[16];                                               // k <= 15 taps + dbeta
-#pragma unroll
-  for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+  float acc = 0.f;
+#pragma unroll 4
   for (int o = tid; o < BC; o += kBlock) {
-    const int b = o / g.C, c = o - b * g.C;
     const float w = A.c.w[o], gg = A.s.gg[o];
-    const float gy1 = a * gg * w * (1.f - w);
-    acc[15] += gg * (w - 0.5f);
-    const float* avg_b = A.c.avg + static_cast<size_t>(b) * g.C;
-#pragma unroll
-    for (int t = 0; t < 15; ++t) {
-      const int cc = c + t - pad;
-      if (t < k && cc >= 0 && cc < g.C) acc[t] += gy1 * avg_b[cc];
+    if (r == kEcaRoles - 1) {
+      acc += gg * (w - 0.5f);
+    } else {
+      const int b = o / g.C, c = o - b * g.C, cc = c + r - pad;
+      if (cc >= 0 && cc < g.C) acc += a * gg * w * (1.f - w) * A.c.avg[static_cast<size_t>(b) * g.C + cc];
     }
   }
-  for (int t = 0; t < 16; ++t) {
-    if (t < k || t == 15) {
-      const float v = block_sum(acc[t], tid, red);
-      if (tid == 0) { if (t == 15) *A.gbeta = sigmoidf_(*A.beta) * v; else A.gw[t] = v; }
-    }
-  }
+  acc = block_sum(acc, tid, red);
+  if (tid == 0) { if (r == kEcaRoles - 1) *A.gbeta = sigmoidf_(*A.beta) * acc; else A.gw[r] = acc; }
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_eca_bwd: gx = gy*g + g_avg*wA ; gmask = (use/den) * (sum_c g_avg*x - K_b) * s(1-s)          (tile layout of k_bwd_apply)
 //   prologue per workgroup (its sample): gy1 = a*gg*w(1-w) -> LDS; g_avg = conv1d^T(gy1) ; q[c] = {g, g_avg} ; K_b
-//   the level's first workgroup is the parameter-gradient role (dW1d, dbeta)
+//   the level's first 16 workgroups are the parameter-gradient roles (dW1d taps, dbeta)
 //   LDS: [C gy1][2C q][256*VEC combine]
 // ---------------------------------------------------------------------------------------------
 template <typename T, int VEC, bool GMASK>
@@ -262,8 +258,8 @@ __global__ __launch_bounds__(kBlock) void k_eca_bwd(const Group<EcaBwdArgs> G) {
   int bid;
   const int l = find_level(G, blockIdx.x, bid);
   const EcaBwdArgs& A = G.lv[l];
-  if (bid < 8) { if (bid == 0) eca_params_body(A, red); return; }   // 8 ids keep the streaming ids XCD-aligned
-  bid -= 8;
+  if (bid < kEcaRoles) { eca_params_body(A, bid, red); return; }   // 16 role ids keep the streaming ids XCD-aligned
+  bid -= kEcaRoles;
   const Geo& g = A.g;
   const int tid = threadIdx.x;
   const int TX = A.t.chan_tx, lt = ilog2(TX);
@@ -284,6 +280,14 @@ __global__ __launch_bounds__(kBlock) void k_eca_bwd(const Group<EcaBwdArgs> G) {
   const bool has_mask = A.mask != nullptr;
   const int k = g.k, pad = k / 2;
 
+  constexpr int UN = 2;                                        // first feature vectors are requested before the prologue
+  float g0v[UN][VEC], x0v[UN][VEC];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const size_t co = static_cast<size_t>(min(ty + u * TY, g.C - 1)) * g.HW;
+    load_vec<T, VEC>(gp + co, g0v[u]);
+    if (GMASK) load_vec<T, VEC>(xp + co, x0v[u]);
+  }
   float* s_gy1 = smem;
   float2* s_q = reinterpret_cast<float2*>(smem + g.C);
   float* sm = smem + 3 * g.C;
@@ -315,11 +319,8 @@ __global__ __launch_bounds__(kBlock) void k_eca_bwd(const Group<EcaBwdArgs> G) {
   const float use = A.c.use[b], den = A.c.den[b];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { wA[e] = has_mask ? (use * sv[e] / den + (1.f - use) / N) : 1.f / N; accp[e] = 0.f; }
-#pragma unroll 4
-  for (int c = ty; c < g.C; c += TY) {
-    float gv[VEC], xv[VEC], ov[VEC];
-    load_vec<T, VEC>(gp + static_cast<size_t>(c) * g.HW, gv);
-    if (GMASK) load_vec<T, VEC>(xp + static_cast<size_t>(c) * g.HW, xv);
+  auto emit = [&](const float (&gv)[VEC], const float (&xv)[VEC], int c) {
+    float ov[VEC];
     const float2 q = s_q[c];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -327,6 +328,18 @@ __global__ __launch_bounds__(kBlock) void k_eca_bwd(const Group<EcaBwdArgs> G) {
       if (GMASK) accp[e] += q.y * xv[e];
     }
     if (active) store_vec_stream<T, VEC>(op + static_cast<size_t>(c) * g.HW, ov, A.t.nt_stores);
+  };
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const int c = ty + u * TY;
+    if (c < g.C) emit(g0v[u], x0v[u], c);
+  }
+#pragma unroll 4
+  for (int c = ty + UN * TY; c < g.C; c += TY) {
+    float gv[VEC], xv[VEC];
+    load_vec<T, VEC>(gp + static_cast<size_t>(c) * g.HW, gv);
+    if (GMASK) load_vec<T, VEC>(xp + static_cast<size_t>(c) * g.HW, xv);
+    emit(gv, xv, c);
   }
   if (GMASK) {
 #pragma unroll

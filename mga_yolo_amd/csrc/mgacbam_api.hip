@@ -641,7 +641,7 @@ static int eca_backward_group(EcaBwdArgs* lv, int n, const Sig& sig, hipStream_t
   {
     size_t smem = 0;
     for (int l = 0; l < n; ++l) smem = std::max(smem, (3 * static_cast<size_t>(lv[l].g.C) + kBlock * sig.vec) * sizeof(float));
-    const int grid = fill([&](const EcaBwdArgs& a) { return 8 + xcd_grid(a.g.B, a.nt); });
+    const int grid = fill([&](const EcaBwdArgs& a) { return kEcaRoles + xcd_grid(a.g.B, a.nt); });
 #define CALL_EB(Tt, Vv) if (sig.gmask) LAUNCH((k_eca_bwd<Tt, Vv, true>), grid, smem, st, G); else LAUNCH((k_eca_bwd<Tt, Vv, false>), grid, smem, st, G)
     DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_EB);
 #undef CALL_EB

@@ -110,3 +110,53 @@ class PyramidPlan:
 
     def named_param_grads(self, level: int) -> dict:
         return dict(zip(("g" + n for n in PARAM_NAMES), self.param_grads[level]))
+
+
+class EcaPyramidPlan:
+    """The same static executor for MaskECA: per level x, mask, y, gy, gx, gmask, ctx, scratch and one flat bucket
+    with the parameter gradients (conv1d.weight, beta) of all levels; ``forward`` / ``backward`` = one library call each
+    (2 kernel launches each for all levels together)."""
+
+    def __init__(self, shapes, params, cfgs, dtype=torch.float32, device="cuda", with_mask=True, want_gmask=True):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.n, self.shapes, self.cfgs, self.dtype = len(shapes), list(shapes), list(cfgs), dtype
+        dev = self.device
+        self.params = [[p.detach().to(dev, torch.float32).contiguous() for p in ps] for ps in params]
+        self.x, self.mask, self.y, self.gy, self.gx, self.gmask, self.ctx, self.scratch = ([] for _ in range(8))
+        self.grad_bucket = torch.zeros(sum(p.numel() for ps in self.params for p in ps), dtype=torch.float32, device=dev)
+        self.param_grads = []
+        self._fwd, self._bwd = (_lib.EcaFwdLevel * self.n)(), (_lib.EcaBwdLevel * self.n)()
+        off = 0
+        ptr = lambda t: None if t is None else t.data_ptr()
+        for l, ((B, C, H, W), (w, beta), cfg) in enumerate(zip(shapes, self.params, cfgs)):
+            mk = lambda *s_, dt=dtype: torch.zeros(*s_, dtype=dt, device=dev)
+            self.x.append(mk(B, C, H, W)); self.y.append(mk(B, C, H, W)); self.gy.append(mk(B, C, H, W)); self.gx.append(mk(B, C, H, W))
+            self.mask.append(mk(B, 1, H, W, dt=torch.float32) if with_mask else None)
+            self.gmask.append(mk(B, 1, H, W, dt=torch.float32) if (with_mask and want_gmask) else None)
+            self.ctx.append(torch.zeros(self.lib.mgacbam_eca_ctx_bytes(B, C, H, W), dtype=torch.uint8, device=dev))
+            self.scratch.append(torch.zeros(self.lib.mgacbam_eca_scratch_bytes(B, C, H, W), dtype=torch.uint8, device=dev))
+            gw = self.grad_bucket[off:off + w.numel()].view(w.shape); off += w.numel()
+            gb = self.grad_bucket[off:off + 1].view(()); off += 1
+            self.param_grads.append([gw, gb])
+            P = _lib.EcaParams(w.data_ptr(), beta.data_ptr(), cfg.k, int(cfg.use_sigmoid_mask), cfg.tiny_thr, cfg.eps)
+            F, Bw = self._fwd[l], self._bwd[l]
+            F.x, F.mask, F.y, F.ctx, F.p = ptr(self.x[l]), ptr(self.mask[l]), ptr(self.y[l]), ptr(self.ctx[l]), P
+            F.B, F.C, F.H, F.W, F.dtype = B, C, H, W, _DTYPES[dtype]
+            Bw.x, Bw.mask, Bw.gy, Bw.ctx, Bw.scratch = ptr(self.x[l]), ptr(self.mask[l]), ptr(self.gy[l]), ptr(self.ctx[l]), ptr(self.scratch[l])
+            Bw.gx, Bw.gmask, Bw.gw, Bw.gbeta, Bw.p = ptr(self.gx[l]), ptr(self.gmask[l]), gw.data_ptr(), gb.data_ptr(), P
+            Bw.B, Bw.C, Bw.H, Bw.W, Bw.dtype = B, C, H, W, _DTYPES[dtype]
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def forward(self):
+        _lib.check(self.lib.mgacbam_eca_forward(self._fwd, self.n, self._stream()), "mgacbam_eca_forward")
+
+    def backward(self):
+        _lib.check(self.lib.mgacbam_eca_backward(self._bwd, self.n, self._stream()), "mgacbam_eca_backward")
+
+    capture = PyramidPlan.capture
+
+    def elements(self) -> int:
+        return sum(B * C * H * W for B, C, H, W in self.shapes)
