@@ -19,6 +19,14 @@
 #include "common.cuh"
 #include "fwd.cuh"   // ConvTile / stage_window
 
+// tuning hooks (A/B builds): unroll 1/2/4/8 and prefetch 1/2 of k_bwd_apply all measure within noise (54.5-57.7 us)
+#ifndef MGACBAM_BAPPLY_UNROLL
+#define MGACBAM_BAPPLY_UNROLL 4
+#endif
+#ifndef MGACBAM_BAPPLY_UN
+#define MGACBAM_BAPPLY_UN 2
+#endif
+
 namespace mgacbam {
 
 // ---------------------------------------------------------------------------------------------
@@ -499,7 +507,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_params(const Group<BwdArgs> G) {
 // ---------------------------------------------------------------------------------------------
 template <typename T, int VEC, bool GMASK>
 __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, float* smem, float* red) {
-  constexpr int UN = 2;
+  constexpr int UN = MGACBAM_BAPPLY_UN;
   const Geo& g = A.g;
   const int tid = threadIdx.x;
   const int TX = A.t.chan_tx, lt = ilog2(TX);
@@ -621,7 +629,7 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
     const int c = ty + u * TY;
     if (c < g.C) emit(g0v[u], x0v[u], c);
   }
-#pragma unroll 4
+#pragma unroll MGACBAM_BAPPLY_UNROLL
   for (int c = ty + UN * TY; c < g.C; c += TY) {
     float gv[VEC], xv[VEC];
     load_vec<T, VEC>(gp + static_cast<size_t>(c) * g.HW, gv);
