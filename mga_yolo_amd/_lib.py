@@ -131,17 +131,28 @@ def check(rc: int, what: str):
         raise RuntimeError(f"{what}: {kind} {rc}: {msg}")
 
 
+_size_cache = {}     # (fn, shape...) -> bytes: the eager path asks on every call; the answer only depends on the shape
+
+
 def ctx_bytes(B, Cc, H, W, hidden) -> int:
-    n = load().mgacbam_ctx_bytes(B, Cc, H, W, hidden)
-    if n == 0:
-        check(-2, "mgacbam_ctx_bytes")
+    key = ("ctx", B, Cc, H, W, hidden)
+    n = _size_cache.get(key)
+    if n is None:
+        n = load().mgacbam_ctx_bytes(B, Cc, H, W, hidden)
+        if n == 0:
+            check(-2, "mgacbam_ctx_bytes")
+        _size_cache[key] = n
     return n
 
 
 def scratch_bytes(B, Cc, H, W, hidden, k) -> int:
-    n = load().mgacbam_bwd_scratch_bytes(B, Cc, H, W, hidden, k)
-    if n == 0:
-        check(-2, "mgacbam_bwd_scratch_bytes")
+    key = ("scratch", B, Cc, H, W, hidden, k)
+    n = _size_cache.get(key)
+    if n is None:
+        n = load().mgacbam_bwd_scratch_bytes(B, Cc, H, W, hidden, k)
+        if n == 0:
+            check(-2, "mgacbam_bwd_scratch_bytes")
+        _size_cache[key] = n
     return n
 
 

@@ -35,7 +35,8 @@ SLOTS = 8  # tensors per level in the flat argument list: x, mask, w1, b1, w2, b
 
 
 def _aligned(t: torch.Tensor) -> torch.Tensor:
-    t = t.contiguous()
+    if not t.is_contiguous():
+        t = t.contiguous()
     if t.data_ptr() % 16:
         t = t.clone(memory_format=torch.contiguous_format)
     return t
