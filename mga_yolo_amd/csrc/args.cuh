@@ -47,8 +47,7 @@ struct FwdArgs {
 
 // transient backward buffers (device pointers into the caller's scratch buffer)
 struct ScratchPtrs {
-  float* A_part;    // (B,C,nt)  sum over one hw tile of gy*x*sa
-  float* Q_part;    // (B,C,nt)  sum over one hw tile of gy*x
+  float* A_part;    // (B,nt,2,C) per hw-tile partials: [0] sum gy*x*sa, [1] sum gy*x (k_bwd_reduce1 -> k_bwd_reduce2)
   float* gpre;      // (B,HW)    dL/d(conv output)
   float* gplanes;   // (B,3,HW)  dL/d(planes)
   float* gwsa_part; // (nconv, 3*k*k)
@@ -56,8 +55,6 @@ struct ScratchPtrs {
   float* gbq;       // (B,C)     ca*A - Q  (for dL/dbeta)
   float* gh_avg;    // (B,hidden)
   float* gh_mx;     // (B,hidden)
-  float* chan4;     // (B,C,4)   {ca, g_avg, g_mx at arg-max, g_mx / N when GAP fallback}
-  float* Kb;        // (B)       (unused since v3)
   float* pgh;       // (B,ncg,hidden) per-channel-group partials of W2^T g_z (k_bwd_reduce2 -> k_bwd_apply prologue)
 };
 

@@ -165,7 +165,7 @@ static int chan_tiles(const Tune& t, int H, int W, int vec) {
   return (nv + t.chan_tx - 1) / t.chan_tx;
 }
 
-struct ScratchLayout { size_t A_part, Q_part, gpre, gplanes, gwsa_part, gz, gbq, gh_avg, gh_mx, chan4, Kb, pgh, total; };
+struct ScratchLayout { size_t A_part, gpre, gplanes, gwsa_part, gz, gbq, gh_avg, gh_mx, pgh, total; };
 static ScratchLayout scratch_layout(int B, int C, int H, int W, int hidden, int k) {
   const Tune t = choose_tune(B, C, H, W, k);
   const size_t HW = static_cast<size_t>(H) * W, BC = static_cast<size_t>(B) * C;
@@ -173,12 +173,11 @@ static ScratchLayout scratch_layout(int B, int C, int H, int W, int hidden, int 
   ScratchLayout L;
   size_t o = 0;
   auto take = [&](size_t n_elems) { size_t at = o; o = align16(o + n_elems * 4); return at; };
-  L.A_part = take(2 * BC * nt); L.Q_part = take(4);       // tile partials of A and Q live together: (B, nt, 2, C)
+  L.A_part = take(2 * BC * nt);                          // tile partials of A and Q live together: (B, nt, 2, C)
   L.gpre = take(B * HW); L.gplanes = take(static_cast<size_t>(B) * 3 * HW);
   L.gwsa_part = take(nconv * 3 * k * k);
   L.gz = take(BC); L.gbq = take(BC);
   L.gh_avg = take(static_cast<size_t>(B) * hidden); L.gh_mx = take(static_cast<size_t>(B) * hidden);
-  L.chan4 = take(4); L.Kb = take(B);
   const size_t ty = kBlock / t.pool_tx;                               // channel groups per sample, worst case (1 channel per row)
   L.pgh = take(static_cast<size_t>(B) * ((C + ty - 1) / ty) * hidden);
   L.total = o;
@@ -411,12 +410,11 @@ static int backward_args(const mgacbam_bwd_level_t& L, BwdArgs& A, Sig& sig) {
   A.t = choose_tune(L.B, L.C, L.H, L.W, L.p.k, L.dtype);
   const ScratchLayout SL = scratch_layout(L.B, L.C, L.H, L.W, L.p.hidden, L.p.k);
   char* sp = static_cast<char*>(L.scratch);
-  A.s.A_part = reinterpret_cast<float*>(sp + SL.A_part); A.s.Q_part = reinterpret_cast<float*>(sp + SL.Q_part);
+  A.s.A_part = reinterpret_cast<float*>(sp + SL.A_part);
   A.s.gpre = reinterpret_cast<float*>(sp + SL.gpre); A.s.gplanes = reinterpret_cast<float*>(sp + SL.gplanes);
   A.s.gwsa_part = reinterpret_cast<float*>(sp + SL.gwsa_part);
   A.s.gz = reinterpret_cast<float*>(sp + SL.gz); A.s.gbq = reinterpret_cast<float*>(sp + SL.gbq);
   A.s.gh_avg = reinterpret_cast<float*>(sp + SL.gh_avg); A.s.gh_mx = reinterpret_cast<float*>(sp + SL.gh_mx);
-  A.s.chan4 = reinterpret_cast<float*>(sp + SL.chan4); A.s.Kb = reinterpret_cast<float*>(sp + SL.Kb);
   A.s.pgh = reinterpret_cast<float*>(sp + SL.pgh);
   A.nt = chan_tiles(A.t, A.g.H, A.g.W, VEC);
   A.nconv = A.g.B * conv_tiles(A.t, A.g.H, A.g.W);

@@ -342,3 +342,61 @@ def test_generic_spatial_kernel_sizes(F, k):
     assert rel_err(y, y_o) < TOL
     for name in GRADS:
         assert rel_err(g[name], g_o[name]) < TOL, name
+
+
+@pytest.mark.parametrize("shape,dtype,tol", [((2, 256, 160, 160), torch.bfloat16, 3e-2), ((2, 512, 40, 40), torch.float16, 4e-3),
+                                             ((2, 512, 20, 20), torch.bfloat16, 3e-2), ((1, 768, 40, 40), torch.float32, 1e-4)])
+def test_config5_shapes_low_precision(F, shape, dtype, tol):
+    """BASELINE.json configs[4] (YOLOv8l widths, 640/1280 inputs, bf16) and the x-scale width: large C / hidden (32, 48) takes
+    the general MLP paths; half-precision I/O with fp32 statistics, against the fp32 oracle on the rounded inputs."""
+    B, C, H, W = shape
+    x, mask, gy = synth(B, C, H, W, seed=91, mask_kind="sparse")
+    x, gy = x.to(dtype).float(), gy.to(dtype).float()
+    p = O.Params.default_init(C, seed=5)
+    y_o, ctx = O.forward(x, mask, p)
+    g_o = O.backward(gy, x, mask, p, O.Config(), ctx)
+    xd = x.cuda().to(dtype).requires_grad_(True)
+    md = mask.cuda().requires_grad_(True)
+    ps = [t_.cuda().requires_grad_(True) for t_ in (p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta)]
+    y = F.mask_cbam(xd, md, *ps, F.BlockConfig(hidden=p.w1.shape[0]))
+    y.backward(gy.cuda().to(dtype))
+    assert rel_err(y.float(), y_o) < tol and rel_err(xd.grad.float(), g_o["gx"]) < tol and rel_err(md.grad, g_o["gmask"]) < tol
+    for got, k in zip(ps, ("gw1", "gb1", "gw2", "gb2", "gwsa", "gbeta")):
+        assert rel_err(got.grad, g_o[k]) < tol, k
+
+
+def test_reentrant_from_two_threads_on_two_streams(F):
+    """The C ABI keeps no mutable global state: two host threads driving different shapes on different streams at once give
+    the same bits as the same calls made one after the other."""
+    import threading
+    jobs = []
+    for i, (B, C, H, W) in enumerate([(8, 64, 40, 40), (4, 128, 20, 20)]):
+        x, mask, gy = synth(B, C, H, W, seed=60 + i)
+        p = O.Params.default_init(C, seed=i)
+        jobs.append(dict(x=x.cuda(), mask=mask.cuda(), gy=gy.cuda(), ps=[t_.cuda() for t_ in (p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta)],
+                         cfg=F.BlockConfig(hidden=p.w1.shape[0])))
+
+    def run(j, stream, out):
+        with torch.cuda.stream(stream):
+            for _ in range(20):
+                x = j["x"].clone().requires_grad_(True)
+                m = j["mask"].clone().requires_grad_(True)
+                y = F.mask_cbam(x, m, *j["ps"], j["cfg"])
+                y.backward(j["gy"])
+            out.append((y.detach().clone(), x.grad.clone(), m.grad.clone()))
+        stream.synchronize()
+
+    serial = [[], []]
+    for j, o in zip(jobs, serial):
+        run(j, torch.cuda.current_stream(), o)
+    torch.cuda.synchronize()
+    par = [[], []]
+    ths = [threading.Thread(target=run, args=(j, torch.cuda.Stream(), o)) for j, o in zip(jobs, par)]
+    for t_ in ths:
+        t_.start()
+    for t_ in ths:
+        t_.join()
+    torch.cuda.synchronize()
+    for s_, p_ in zip(serial, par):
+        for a, b in zip(s_[0], p_[0]):
+            assert torch.equal(a, b)
