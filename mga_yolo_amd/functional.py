@@ -42,6 +42,22 @@ def _aligned(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def _ready(t: torch.Tensor) -> torch.Tensor:
+    """Detached, contiguous, 16-byte aligned view/copy of t; the common case (already so) costs two attribute reads."""
+    if t.is_contiguous() and t.data_ptr() % 16 == 0:
+        return t                                               # (inside autograd.Function.forward: no graph is recorded)
+    return _aligned(t.detach())
+
+
+def _mask32(mask: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
+    m = mask
+    if m.dim() == 3:
+        m = m.unsqueeze(1)
+    if m.dtype != torch.float32:
+        m = m.float()
+    return _ready(m)
+
+
 def _check_level(x: torch.Tensor, mask: Optional[torch.Tensor], params: Sequence[torch.Tensor], cfg: BlockConfig):
     if x.dim() != 4:
         raise AssertionError("MaskCBAM expects a (B,C,H,W) feature")          # masked_cbam.py:160
@@ -85,9 +101,9 @@ class _PyramidFn(torch.autograd.Function):
                 raise RuntimeError("mask_cbam: all features must live on the same GPU")
             _check_level(x, mask, params, cfg)
             B, Cc, H, W = x.shape
-            xc = _aligned(x.detach())
-            m32 = None if mask is None else _aligned(mask.detach().reshape(B, 1, H, W).float())
-            pc = [_aligned(p.detach()) for p in params]
+            xc = _ready(x)
+            m32 = None if mask is None else _mask32(mask, B, H, W)
+            pc = [_ready(p) for p in params]
             y = torch.empty_like(xc)
             cbuf = torch.empty(_lib.ctx_bytes(B, Cc, H, W, cfg.hidden), dtype=torch.uint8, device=dev)
             L = levels[l]

@@ -110,15 +110,19 @@ class MaskCBAM(nn.Module):
 
     @property
     def hidden(self) -> int:
-        return self.cam_mlp[0].out_features
+        return self.cam_mlp._modules["0"].out_features
 
     def block_config(self) -> BlockConfig:
-        return BlockConfig(hidden=self.hidden, k=self.k, use_sigmoid_mask=bool(self.use_sigmoid_mask),
-                           tiny_thr=float(self.tiny_thr), eps=float(self.eps))
+        key = (self.hidden, self.k, bool(self.use_sigmoid_mask), float(self.tiny_thr), float(self.eps))
+        cached = self.__dict__.get("_cfg_cache")
+        if cached is None or cached[0] != key:                 # attributes are plain and may be edited after construction
+            cached = (key, BlockConfig(*key))
+            self.__dict__["_cfg_cache"] = cached
+        return cached[1]
 
     def block_params(self):
-        return (self.cam_mlp[0].weight, self.cam_mlp[0].bias, self.cam_mlp[2].weight, self.cam_mlp[2].bias,
-                self.sam_conv.weight, self.beta)
+        l1, l2 = self.cam_mlp._modules["0"], self.cam_mlp._modules["2"]     # (Sequential.__getitem__ is slow on the hot path)
+        return (l1.weight, l1.bias, l2.weight, l2.bias, self.sam_conv.weight, self.beta)
 
     def forward(self, x: Union[torch.Tensor, Sequence[torch.Tensor]]) -> torch.Tensor:
         if isinstance(x, (list, tuple)):
