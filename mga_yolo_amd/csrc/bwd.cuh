@@ -1,19 +1,23 @@
 // Backward kernels of the mask-guided CBAM block: the gradients autograd derives for
 // mga_yolo/nn/modules/masked_cbam.py:87-171, restated in SURVEY.md section 8a and oracle/maskcbam_oracle.py.
 //
-// With a = softplus(beta), u = x*ca, v = u*sa, N = H*W:
+// With a = softplus(beta), u = x*ca, v = u*sa, N = H*W; four launches per step, each covering P3+P4+P5:
 //   k_bwd_reduce1  x, gy (1 read each) -> A[b,c] = sum_hw gy*x*sa, Q[b,c] = sum_hw gy*x   (per hw-tile partials)
 //                                         g_pre[b,hw] = a * sa(1-sa) * sum_c ca*gy*x
-//   k_bwd_convT    g_pre, planes       -> g_planes = conv_transpose(g_pre, Wsa) ; per-tile partials of dWsa     [tiny]
-//   k_bwd_reduce2  x (1 read)          -> g_ca[b,c] = a*A + sum_hw x * ([c == cidx]*gp0 + gp1/C) ; g_z ; (ca*A - Q)
-//   k_bwd_params   g_z, partials       -> dW1 db1 dW2 db2 dWsa dbeta and g_h (relu-masked) per sample            [tiny]
-//   k_bwd_apply    gy (+ x when dL/dmask is wanted) -> prologue: g_avg, g_mx = W1^T g_h ; body: gx (1 write), gmask
+//   k_bwd_convT    g_pre               -> g_planes = conv_transpose(g_pre, Wsa)                    [tiny, critical path]
+//   k_bwd_reduce2  x (1 read)          -> g_ca[b,c] = a*A + sum_hw x * ([c == cidx]*gp0 + gp1/C) ; g_z ; (ca*A - Q) ;
+//                                         per-channel-group partials of W2^T g_z
+//                                         + role workgroups (k_bwd_wsa body): dWsa tile partials
+//   k_bwd_apply    gy (+ x when dL/dmask is wanted) -> prologue: g_h from the partials, g_avg, g_mx = W1^T g_h ;
+//                                         body: gx (1 write), gmask
+//                                         + role workgroups (k_bwd_params body): dW1 db1 dW2 db2 dWsa dbeta
+//   (k_bwd_wsa / k_bwd_params also exist as stand-alone launches: MGACBAM_BWD_PARAMS, the split form for callers that want
+//    the parameter gradients complete before the largest kernel runs.)
 //
 // Algebra that keeps traffic at 2+1+3 passes: the term of g_ca that needs g_planes only needs x (not gy),
 // and gx needs gy, the saved arg-max indices and planes but x only for the masked-average part of dL/dmask.
-// All cross-workgroup sums are two-stage (partials, then one reader), never float atomics, so results are
-// bitwise reproducible run to run.  Every parameter gradient is complete after k_bwd_params, i.e. BEFORE the
-// largest kernel (k_bwd_apply) runs, so a data-parallel all-reduce of them overlaps it.
+// All cross-workgroup sums are two-stage (partials, then one reader, fixed order), never float atomics, so results are
+// bitwise reproducible run to run.
 #pragma once
 #include "args.cuh"
 #include "common.cuh"
