@@ -27,6 +27,9 @@
 #ifndef MGACBAM_BAPPLY_UNROLL
 #define MGACBAM_BAPPLY_UNROLL 4
 #endif
+#ifndef MGACBAM_EARLY_H
+#define MGACBAM_EARLY_H 8    // hidden sizes up to this issue k_bwd_apply's second-phase prologue loads early
+#endif
 #ifndef MGACBAM_BAPPLY_UN
 #define MGACBAM_BAPPLY_UN 2
 #endif
@@ -571,6 +574,19 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
   const int h = g.hidden;
   const float live = (has_mask && A.c.S[b] >= g.eps) ? 1.f : 0.f;   // clamp_min passes grad only when not clamped
   float kpart = 0.f;
+  // common sizes (one channel per thread, hidden <= 16): the per-channel operands of the second prologue phase do not depend
+  // on the first, so they are requested now; 20 registers, live only until the main loop starts
+  constexpr int kEarlyH = MGACBAM_EARLY_H;
+  const bool early = g.C <= kBlock && h <= kEarlyH;
+  float rw1[kEarlyH], rca = 0.f, rmavg = 0.f;
+  int rvalid = 0, ramax = 0;
+  if (early) {
+    const int c = min(tid, g.C - 1);
+    const size_t o = static_cast<size_t>(b) * g.C + c;
+    rca = A.c.ca[o]; rmavg = A.c.mavg[o]; rvalid = A.c.valid[o]; ramax = amax[c];
+#pragma unroll
+    for (int j = 0; j < kEarlyH; ++j) rw1[j] = A.p.w1[static_cast<size_t>(min(j, h - 1)) * g.C + c];
+  }
   {
     // hidden gradient of this sample: g_h[j] = sum over channel groups of k_bwd_reduce2's partials (fixed order),
     // relu-masked for the two applications of the shared MLP
@@ -593,19 +609,37 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
       __syncthreads();
     }
   }
-  for (int c = tid; c < g.C; c += kBlock) {
-    float ga = 0.f, gm = 0.f;
-    for (int j = 0; j < h; ++j) { const float wv = A.p.w1[static_cast<size_t>(j) * g.C + c]; ga += wv * s_gh[j]; gm += wv * s_gh[h + j]; }
-    const size_t o = static_cast<size_t>(b) * g.C + c;
-    const int valid = A.c.valid[o];
-    float4 q;
-    q.x = A.c.ca[o];
-    q.y = ga;
-    q.z = valid ? gm : 0.f;
-    q.w = valid ? 0.f : gm / N;
-    s_q[c] = q;
-    s_am[c] = valid ? amax[c] : -1;
-    kpart += ga * A.c.mavg[o] * live;
+  if (early) {
+    // per-channel operands were requested before the partial-sum barriers (one global-load latency instead of two)
+    if (tid < g.C) {
+      float ga = 0.f, gm = 0.f;
+#pragma unroll
+      for (int j = 0; j < kEarlyH; ++j)
+        if (j < h) { ga += rw1[j] * s_gh[j]; gm += rw1[j] * s_gh[h + j]; }
+      float4 q;
+      q.x = rca;
+      q.y = ga;                               // g_avg
+      q.z = rvalid ? gm : 0.f;                // routed to the arg-max position
+      q.w = rvalid ? 0.f : gm / N;            // GAP fallback: spread uniformly
+      s_q[tid] = q;
+      s_am[tid] = rvalid ? ramax : -1;
+      kpart += ga * rmavg * live;
+    }
+  } else {
+    for (int c = tid; c < g.C; c += kBlock) {
+      float ga = 0.f, gm = 0.f;
+      for (int j = 0; j < h; ++j) { const float wv = A.p.w1[static_cast<size_t>(j) * g.C + c]; ga += wv * s_gh[j]; gm += wv * s_gh[h + j]; }
+      const size_t o = static_cast<size_t>(b) * g.C + c;
+      const int valid = A.c.valid[o];
+      float4 q;
+      q.x = A.c.ca[o];
+      q.y = ga;
+      q.z = valid ? gm : 0.f;
+      q.w = valid ? 0.f : gm / N;
+      s_q[c] = q;
+      s_am[c] = valid ? amax[c] : -1;
+      kpart += ga * A.c.mavg[o] * live;
+    }
   }
 
   kpart = block_sum(kpart, tid, red);       // (contains the barriers that publish s_q)
