@@ -27,6 +27,8 @@
 #ifndef MGACBAM_BAPPLY_UNROLL
 #define MGACBAM_BAPPLY_UNROLL 4
 #endif
+constexpr int kPghLds = 2048;   // floats of LDS for k_bwd_reduce2's hidden-gradient partials (rows x hidden chunk)
+
 #ifndef MGACBAM_EARLY_H
 #define MGACBAM_EARLY_H 8    // hidden sizes up to this issue k_bwd_apply's second-phase prologue loads early
 #endif
@@ -364,20 +366,25 @@ __device__ __forceinline__ void bwd_reduce2_body(const BwdArgs& A, const int bid
   // this workgroup's share of the hidden gradient: pgh[b,cg,j] = sum_{c in group} W2[c,j] * g_z[b,c]
   // (k_bwd_apply sums the groups in its prologue, so it does not wait for the parameter-gradient kernel)
   const int h = g.hidden;
-  float* s_pg = red + 64;                                      // TY x h
-  if (tx == 0) {
-    for (int jh = 0; jh < h; ++jh) {
-      float p = 0.f;
+  float* s_pg = red + 64;                                      // TY x hc (hidden units are processed in chunks of hc)
+  const int hc = min(h, max(1, kPghLds / TY));
+  for (int h0 = 0; h0 < h; h0 += hc) {
+    const int hn = min(hc, h - h0);
+    if (h0) __syncthreads();
+    if (tx == 0) {
+      for (int jh = 0; jh < hn; ++jh) {
+        float p = 0.f;
 #pragma unroll
-      for (int j = 0; j < CPT; ++j) p += A.p.w2[static_cast<size_t>(cj[j]) * h + jh] * gzv[j];
-      s_pg[ty * h + jh] = p;
+        for (int j = 0; j < CPT; ++j) p += A.p.w2[static_cast<size_t>(cj[j]) * h + h0 + jh] * gzv[j];
+        s_pg[ty * hc + jh] = p;
+      }
     }
-  }
-  __syncthreads();
-  for (int jh = tid; jh < h; jh += kBlock) {
-    float p = 0.f;
-    for (int r = 0; r < TY; ++r) p += s_pg[r * h + jh];
-    A.s.pgh[(static_cast<size_t>(b) * ncg + cg) * h + jh] = p;
+    __syncthreads();
+    for (int jh = tid; jh < hn; jh += kBlock) {
+      float p = 0.f;
+      for (int r = 0; r < TY; ++r) p += s_pg[r * hc + jh];
+      A.s.pgh[(static_cast<size_t>(b) * ncg + cg) * h + h0 + jh] = p;
+    }
   }
 }
 

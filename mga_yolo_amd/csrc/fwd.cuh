@@ -362,16 +362,17 @@ __global__ __launch_bounds__(kBlock) void k_chan(const Group<FwdArgs> G) {
 template <int U, typename SrcFn>
 __device__ __forceinline__ void stage_window(float* tile, int NP, int PH, int PW, int ya, int xa, const Geo& g, SrcFn src) {
   const int total = NP * PH * PW;
-  const unsigned mpw = 0xFFFFFFFFu / static_cast<unsigned>(PW) + 1u;    // idx / PW == umulhi(idx, mpw) for idx < 2^16
-  const unsigned mph = 0xFFFFFFFFu / static_cast<unsigned>(PH) + 1u;
+  // idx / d == umulhi(idx, 2^32/d + 1) for idx < 2^16; d == 1 would overflow the magic, so it gets the identity
+  const unsigned mpw = PW > 1 ? 0xFFFFFFFFu / static_cast<unsigned>(PW) + 1u : 0u;
+  const unsigned mph = PH > 1 ? 0xFFFFFFFFu / static_cast<unsigned>(PH) + 1u : 0u;
   for (int base = 0; base < total; base += kBlock * U) {
     float v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int idx = base + u * kBlock + threadIdx.x;
-      const unsigned r = __umulhi(static_cast<unsigned>(idx), mpw);        // row over all planes
+      const unsigned r = PW > 1 ? __umulhi(static_cast<unsigned>(idx), mpw) : static_cast<unsigned>(idx);   // row over all planes
       const int xx = idx - static_cast<int>(r) * PW;
-      const unsigned p = __umulhi(r, mph);
+      const unsigned p = PH > 1 ? __umulhi(r, mph) : r;
       const int yy = static_cast<int>(r) - static_cast<int>(p) * PH;
       const int gy_ = ya + yy, gx_ = xa + xx;
       v[u] = 0.f;

@@ -466,7 +466,7 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
   if (stages & MGACBAM_BWD_REDUCE2) {  // 3. rest of g_ca (needs g_planes), g_z [+ dWsa partials as role workgroups]
     size_t smem = 0;
     for (int l = 0; l < n; ++l) {
-      smem = std::max(smem, (64 + static_cast<size_t>(kBlock / lv[l].t.pool_tx) * lv[l].g.hidden) * sizeof(float));
+      smem = std::max(smem, (64 + static_cast<size_t>(std::max(kPghLds, kBlock / lv[l].t.pool_tx))) * sizeof(float));
       if (fuse_wsa) smem = std::max(smem, wsa_smem(lv[l].t, sig.k));
     }
     const int grid = fill([&](const BwdArgs& a) { return (fuse_wsa ? pad8(a.nwsa) : 0) + sweep_blocks(a, a.t.pool_tx, cpt); });

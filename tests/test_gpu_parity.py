@@ -400,3 +400,29 @@ def test_reentrant_from_two_threads_on_two_streams(F):
     for s_, p_ in zip(serial, par):
         for a, b in zip(s_[0], p_[0]):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,C,H,W,k,r,kind", [
+    (3, 64, 14, 27, 1, 16, "mixed"),      # k = 1, H*W odd: the conv prologue stages a 1-row window (divide-by-one index magic)
+    (16, 130, 23, 1, 1, 16, "sparse"),    # W = 1: 1-column windows
+    (9, 256, 28, 1, 7, 1, "randn"),       # r = 1: hidden = C = 256 with one lane per row (LDS chunking of the hidden partials)
+    (2, 320, 2, 12, 3, 1, "randn"),
+    (8, 320, 8, 3, 9, 1, "prob"),
+    (5, 3, 23, 17, 1, 1, "mixed"),
+])
+def test_regressions_found_by_the_fuzzer(F, B, C, H, W, k, r, kind):
+    """Shapes that tools/fuzz_parity.py (randomised parity fuzz, 1000 cases on MI355X) once broke."""
+    x, mask, gy = synth(B, C, H, W, seed=5, mask_kind=kind)
+    p = O.Params.default_init(C, r=r, k=k, seed=1)
+    cfg = O.Config(use_sigmoid_mask=kind != "prob")
+    y_o, c = O.forward(x, mask, p, cfg)
+    g_o = O.backward(gy, x, mask, p, cfg, c)
+    d = dict(x=x, mask=mask, gy=gy, params={"cam_mlp.0.weight": p.w1, "cam_mlp.0.bias": p.b1, "cam_mlp.2.weight": p.w2,
+                                            "cam_mlp.2.bias": p.b2, "sam_conv.weight": p.wsa, "beta": p.beta},
+             meta=dict(k=k, use_sigmoid_mask=kind != "prob", tiny_thr=1e-4, eps=1e-6))
+    y, g = _run_gpu(F, d)
+    assert rel_err(y, y_o) < TOL
+    floor = 1e-6 * float(gy.norm() * x.norm())
+    for name in GRADS:
+        tol = TOL * float(g_o[name].abs().max()) + (floor if name not in ("gx",) else 0.0)
+        assert float((g[name].detach().cpu().double() - g_o[name].double()).abs().max()) <= tol, name
