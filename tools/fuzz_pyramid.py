@@ -1,0 +1,56 @@
+"""Randomised fuzz of the multi-level entry point: 2-5 levels per call with mixed shapes, conv sizes, mask / no mask, dtypes of
+their own -- exercises the launch-group partition (levels with different compile-time signatures go to different launches), the
+longest-first level ordering and the XCD-aligned grids.  Every level is checked against the oracle.
+    python tools/fuzz_pyramid.py [n_calls] [seed]"""
+import os, random, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from conftest import rel_err, synth
+from oracle import maskcbam_oracle as O
+from mga_yolo_amd import functional as F
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for it in range(n):
+    nl = rng.randint(2, 5)
+    lv, ref = [], []
+    for l in range(nl):
+        B = rng.choice([1, 2, 4, 8, 11])
+        C = rng.choice([8, 16, 64, 128, 192, 256])
+        H, W = rng.choice([(20, 20), (8, 8), (17, 17), (5, 12), (40, 40), (3, 3)])
+        k = rng.choice([7, 7, 3, 5, 9])
+        kind = rng.choice(["randn", "sparse", "none", "mixed"]) if B > 1 else rng.choice(["randn", "none"])
+        dt = rng.choice([torch.float32, torch.float32, torch.float16, torch.bfloat16])
+        x, mask, gy = synth(B, C, H, W, seed=7000 + 10 * it + l, mask_kind=kind)
+        x, gy = x.to(dt).float(), gy.to(dt).float()
+        p = O.Params.default_init(C, k=k, seed=it + l)
+        y_o, c = O.forward(x, mask, p)
+        g_o = O.backward(gy, x, mask, p, O.Config(), c)
+        xd = x.cuda().to(dt).requires_grad_(True)
+        md = None if mask is None else mask.cuda().requires_grad_(rng.random() < 0.8)
+        ps = [t.cuda().requires_grad_(True) for t in (p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta)]
+        lv.append((xd, md, ps, F.BlockConfig(hidden=p.w1.shape[0], k=k)))
+        ref.append((y_o, g_o, gy, dt, (B, C, H, W, k, kind)))
+    try:
+        ys = F.mask_cbam_pyramid(lv)
+        torch.autograd.backward(list(ys), [r[2].cuda().to(r[3]) for r in ref])
+        for l, ((xd, md, ps, _), (y_o, g_o, gy, dt, desc)) in enumerate(zip(lv, ref)):
+            tol = {torch.float32: 1e-4, torch.float16: 4e-3, torch.bfloat16: 3e-2}[dt]
+            floor = 1e-6 * float(gy.norm() * xd.detach().float().norm().cpu())
+            checks = dict(y=(ys[l].float(), y_o), gx=(xd.grad.float(), g_o["gx"]), gw1=(ps[0].grad, g_o["gw1"]), gwsa=(ps[4].grad, g_o["gwsa"]),
+                          gbeta=(ps[5].grad, g_o["gbeta"]), gw2=(ps[2].grad, g_o["gw2"]))
+            if md is not None and md.requires_grad:
+                checks["gmask"] = (md.grad, g_o["gmask"])
+            for name, (got, want) in checks.items():
+                dv = float((got.detach().double().cpu() - want.double()).abs().max())
+                sc = float(want.double().abs().max()) + (floor if name not in ("y", "gx") else 0.0)
+                if not dv <= tol * max(sc, 1e-30):
+                    bad += 1
+                    print(f"FAIL call {it} level {l} {desc} {dt}: {name} {dv / max(sc, 1e-30):.2e}", flush=True)
+    except Exception as ex:   # noqa: BLE001
+        bad += 1
+        print(f"ERROR call {it}: {[r[4] for r in ref]}: {type(ex).__name__}: {ex}", flush=True)
+print(f"pyramid fuzz: {n} calls, {bad} failures")
+sys.exit(1 if bad else 0)
