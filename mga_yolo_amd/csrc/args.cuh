@@ -28,11 +28,9 @@ struct ParamPtrs { const float* w1; const float* b1; const float* w2; const floa
 
 // launch geometry chosen on the host (api.hip: choose_*); TX = lanes along H*W, power of two
 struct Tune {
-  int pool_tx;     // k_pool / k_bwd_reduce2 : rows of TX lanes sweep H*W, TY = 256/TX rows x CPT channels
+  int pool_tx;     // sweep kernels (k_pool, k_bwd_reduce2, k_eca_*): rows of TX lanes sweep H*W, TY = 256/TX rows x CPT channels
   int pool_cpt;
-  int apply_tx;    // k_apply
-  int apply_cpt;
-  int chan_tx;     // k_chan / k_bwd_reduce1 / k_bwd_apply : one H*W vector per lane, TY = 256/TX channel slices
+  int chan_tx;     // tile kernels (k_chan, k_apply, k_bwd_reduce1, k_bwd_apply, k_eca_bwd): one H*W vector per lane, TY = 256/TX channel slices
   int conv_twq;    // backward conv tiles: TWQ quads (4 px) wide, TH rows
   int conv_th;
   int wsa_th;      // k_bwd_wsa tiles: fewer rows so 4 staged planes stay under ~16 KB of LDS (role workgroups)

@@ -114,7 +114,6 @@ static Tune choose_tune(int B, int C, int H, int W, int k, int dtype = MGACBAM_F
   int cpt = 4;
   while (cpt > 1 && static_cast<long long>(B) * ((C + (256 / tx) * cpt - 1) / ((256 / tx) * cpt)) < 1024) cpt /= 2;
   t.pool_tx = tx; t.pool_cpt = cpt;
-  t.apply_tx = tx; t.apply_cpt = cpt;
   // one H*W vector per lane, TY channel slices: TX <= 64 so row reductions are pure wave shuffles
   int ctx = pow2_ceil(nv) < 64 ? pow2_ceil(nv) : 64;
   const int min_tx = env_int("MGACBAM_CHAN_MINTX", 16);
@@ -141,8 +140,6 @@ static Tune choose_tune(int B, int C, int H, int W, int k, int dtype = MGACBAM_F
   int v;
   if (is_pow2_in(v = env_int("MGACBAM_POOL_TX", 0), 1, 256)) t.pool_tx = v;
   if ((v = env_int("MGACBAM_POOL_CPT", 0)) == 1 || v == 2 || v == 4) t.pool_cpt = v;
-  if (is_pow2_in(v = env_int("MGACBAM_APPLY_TX", 0), 1, 256)) t.apply_tx = v;
-  if ((v = env_int("MGACBAM_APPLY_CPT", 0)) == 1 || v == 2 || v == 4) t.apply_cpt = v;
   if (is_pow2_in(v = env_int("MGACBAM_CHAN_TX", 0), 1, 64)) t.chan_tx = v;
   // k_apply stages every image row its TX*VEC-pixel tile touches, plus the k-1 halo rows
   int rows = (t.chan_tx * VEC - 1) / W + 2;
@@ -246,13 +243,13 @@ struct Sig {
 // per CU, else 1 (4 is instantiated and reachable through MGACBAM_POOL_CPT, but measured slower at every benchmark shape:
 // k_pool 80 us vs 91 us at config 4, 22 vs 26 us at config 2)
 template <typename Args>
-static int group_cpt(const Args* lv, int n, bool apply_kernel) {
-  const int forced = env_int(apply_kernel ? "MGACBAM_APPLY_CPT" : "MGACBAM_POOL_CPT", 0);
+static int group_cpt(const Args* lv, int n) {
+  const int forced = env_int("MGACBAM_POOL_CPT", 0);
   if (forced == 1 || forced == 2 || forced == 4) return forced;
   for (int cpt = 2; cpt > 1; cpt /= 2) {
     long long blocks = 0;
     for (int l = 0; l < n; ++l) {
-      const int tx = apply_kernel ? lv[l].t.apply_tx : lv[l].t.pool_tx;
+      const int tx = lv[l].t.pool_tx;
       const int cpb = (kBlock / tx) * cpt;
       blocks += static_cast<long long>(lv[l].g.B) * ((lv[l].g.C + cpb - 1) / cpb);   // real workgroups (padding ids exit at once)
     }
@@ -311,7 +308,7 @@ static int forward_args(const mgacbam_fwd_level_t& L, FwdArgs& A, Sig& sig) {
 static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStream_t st) {
   Group<FwdArgs> G;
   G.n = n;
-  const int pool_cpt = group_cpt(lv, n, false);
+  const int pool_cpt = group_cpt(lv, n);
   for (int l = 0; l < n; ++l) { lv[l].t.pool_cpt = pool_cpt; G.lv[l] = lv[l]; }
   auto fill = [&](auto blocks_of) { int tot = 0; for (int l = 0; l < n; ++l) { G.start[l] = tot; tot += blocks_of(lv[l]); } G.start[n] = tot; return tot; };
 
@@ -430,7 +427,7 @@ static int backward_args(const mgacbam_bwd_level_t& L, BwdArgs& A, Sig& sig) {
 static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStream_t st) {
   Group<BwdArgs> G;
   G.n = n;
-  const int cpt = group_cpt(lv, n, false);
+  const int cpt = group_cpt(lv, n);
   for (int l = 0; l < n; ++l) {
     lv[l].t.pool_cpt = cpt;
     const int cpb = (kBlock / lv[l].t.pool_tx) * cpt;
@@ -568,7 +565,7 @@ static Geo eca_geo(int B, int C, int H, int W, const mgacbam_eca_params_t& p) {
 static int eca_forward_group(EcaFwdArgs* lv, int n, const Sig& sig, hipStream_t st) {
   Group<EcaFwdArgs> G;
   G.n = n;
-  const int cpt = group_cpt(lv, n, false);
+  const int cpt = group_cpt(lv, n);
   for (int l = 0; l < n; ++l) { lv[l].t.pool_cpt = cpt; G.lv[l] = lv[l]; }
   auto fill = [&](auto blocks_of) { int tot = 0; for (int l = 0; l < n; ++l) { G.start[l] = tot; tot += blocks_of(lv[l]); } G.start[n] = tot; return tot; };
   const int grid = fill([&](const EcaFwdArgs& a) { return sweep_blocks(a, a.t.pool_tx, cpt); });
@@ -624,7 +621,7 @@ extern "C" int mgacbam_eca_forward(const mgacbam_eca_fwd_level_t* levels, int n_
 static int eca_backward_group(EcaBwdArgs* lv, int n, const Sig& sig, hipStream_t st) {
   Group<EcaBwdArgs> G;
   G.n = n;
-  const int cpt = group_cpt(lv, n, false);
+  const int cpt = group_cpt(lv, n);
   for (int l = 0; l < n; ++l) { lv[l].t.pool_cpt = cpt; G.lv[l] = lv[l]; }
   auto fill = [&](auto blocks_of) { int tot = 0; for (int l = 0; l < n; ++l) { G.start[l] = tot; tot += blocks_of(lv[l]); } G.start[n] = tot; return tot; };
   {

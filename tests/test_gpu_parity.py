@@ -206,11 +206,11 @@ def test_backward_is_linear_in_gy(F):
         assert rel_err(g2[k], -2.5 * g1[k]) < 1e-5, k
 
 
-@pytest.mark.parametrize("env", [dict(MGACBAM_POOL_TX="16", MGACBAM_POOL_CPT="1", MGACBAM_CHAN_TX="16", MGACBAM_APPLY_TX="32", MGACBAM_APPLY_CPT="4"),
-                                 dict(MGACBAM_POOL_TX="64", MGACBAM_POOL_CPT="4", MGACBAM_CHAN_TX="64", MGACBAM_APPLY_TX="256", MGACBAM_APPLY_CPT="1"),
-                                 dict(MGACBAM_POOL_TX="128", MGACBAM_POOL_CPT="2", MGACBAM_CHAN_TX="32", MGACBAM_APPLY_TX="128", MGACBAM_APPLY_CPT="2"),
-                                 dict(MGACBAM_POOL_TX="256", MGACBAM_POOL_CPT="4", MGACBAM_CHAN_TX="8", MGACBAM_APPLY_TX="8", MGACBAM_APPLY_CPT="2"),
-                                 dict(MGACBAM_POOL_TX="1", MGACBAM_POOL_CPT="1", MGACBAM_CHAN_TX="1", MGACBAM_APPLY_TX="2", MGACBAM_APPLY_CPT="1")])
+@pytest.mark.parametrize("env", [dict(MGACBAM_POOL_TX="16", MGACBAM_POOL_CPT="1", MGACBAM_CHAN_TX="16"),
+                                 dict(MGACBAM_POOL_TX="64", MGACBAM_POOL_CPT="4", MGACBAM_CHAN_TX="64"),
+                                 dict(MGACBAM_POOL_TX="128", MGACBAM_POOL_CPT="2", MGACBAM_CHAN_TX="32"),
+                                 dict(MGACBAM_POOL_TX="256", MGACBAM_POOL_CPT="4", MGACBAM_CHAN_TX="8"),
+                                 dict(MGACBAM_POOL_TX="1", MGACBAM_POOL_CPT="1", MGACBAM_CHAN_TX="1")])
 def test_every_launch_geometry_gives_the_same_answer(F, env, monkeypatch):
     """The launch-geometry hooks (rows x lanes, channels per thread) must not change results beyond rounding."""
     for k, v in env.items():
