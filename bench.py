@@ -48,9 +48,9 @@ WORKLOADS = {
 }
 
 # algorithmic bytes of each HBM-bound kernel in units of E*w (feature-sized tensors it must read or write once)
-FWD_KERNEL_E = {"pool": 1, "chan": 1, "apply": 2}
+FWD_KERNEL_E = {"pool": 1, "chan": 1, "apply": 2, "gate": 2}   # k_gate = chan + apply with x resident: read x once, write y
 BWD_KERNEL_E = {"reduce1": 2, "reduce2": 1, "apply": 3}
-KERNEL_SYMBOL = {"fwd.pool": "k_pool", "fwd.chan": "k_chan", "fwd.apply": "k_apply", "bwd.reduce1": "k_bwd_reduce1",
+KERNEL_SYMBOL = {"fwd.pool": "k_pool", "fwd.chan": "k_chan", "fwd.apply": "k_apply", "fwd.gate": "k_gate", "bwd.reduce1": "k_bwd_reduce1",
                  "bwd.reduce2": "k_bwd_reduce2", "bwd.apply": "k_bwd_apply", "bwd.convT": "k_bwd_convT"}
 
 
@@ -97,14 +97,18 @@ def make_plan(workload, device, seed, dtype_name="f32"):
 
 
 def time_kernels(plan, reps):
-    """Mean duration of each of the step's 7 launches, measured IN STEP ORDER (so every kernel sees the cache state the
+    """Mean duration of each of the step's launches, measured IN STEP ORDER (so every kernel sees the cache state the
     previous one leaves, as in the real step): the step is issued eagerly `reps` times with an event before and after each
     library call on the launch stream; elapsed(before, after) brackets exactly one kernel launch."""
     import torch
     from mga_yolo_amd import _lib
     Bs, Fs = _lib.BWD_STAGES, _lib.FWD_STAGES
-    seq = [("fwd.pool", plan.forward, Fs["pool"]), ("fwd.chan", plan.forward, Fs["chan"]), ("fwd.apply", plan.forward, Fs["apply"]),
-           ("bwd.reduce1", plan.backward, Bs["reduce1"]), ("bwd.convT", plan.backward, Bs["convT"]),
+    fwd = [("fwd.pool", plan.forward, Fs["pool"])]
+    if plan.fuse_forward:
+        fwd += [("fwd.gate", plan.forward, Fs["chan"] | Fs["apply"])]     # one x-resident launch (plan adds FWD_FUSE)
+    else:
+        fwd += [("fwd.chan", plan.forward, Fs["chan"]), ("fwd.apply", plan.forward, Fs["apply"])]
+    seq = fwd + [("bwd.reduce1", plan.backward, Bs["reduce1"]), ("bwd.convT", plan.backward, Bs["convT"]),
            # the two fused launches: streaming workgroups + role workgroups (dWsa partials / parameter gradients)
            ("bwd.reduce2", plan.backward, Bs["reduce2"] | Bs["wsa"] | _lib.BWD_FUSE),
            ("bwd.apply", plan.backward, Bs["params"] | Bs["apply"] | _lib.BWD_FUSE)]
@@ -134,7 +138,7 @@ def time_kernels(plan, reps):
     for k, (name, _, _) in enumerate(seq):
         ts = sorted(ev[r][k].elapsed_time(ev[r][k + 1]) * 1e3 for r in range(reps))
         out[name] = sum(ts[:keep]) / keep                       # mean of the fastest 75 % (drops host hiccups)
-    pad = max(0.0, (sum(out.values()) - t_outer) / len(seq))
+    pad = max(0.0, (sum(out.values()) - t_outer) / len(seq))     # (t_outer has the same number of launches)
     out = {k: max(v - pad, 0.0) for k, v in out.items()}
     out["_event_pad_us"] = pad
     return out
@@ -208,13 +212,13 @@ def main():
     def part_a():                # parameter-free prefix of the step: masked pooling
         plan.forward(S["pool"])
 
-    def part_b():                # everything that reads parameters: rest of forward, whole backward (7 launches/step in all)
+    def part_b():                # everything that reads parameters: rest of forward, whole backward (6 launches/step in all)
         plan.forward(S["chan"] | S["apply"])
         plan.backward()
 
-    def whole():
-        part_a()
-        part_b()
+    def whole():                 # N=1: one library call each way (the forward is ONE launch when the plan fuses it)
+        plan.forward()
+        plan.backward()
 
     if args.no_graph:
         run_a, run_b, run_all = part_a, part_b, whole

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MGACBAM_ABI_VERSION 6
+#define MGACBAM_ABI_VERSION 7
 #define MGACBAM_MAX_LEVELS 8          /* P3/P4/P5 need 3 */
 
 enum { MGACBAM_F32 = 0, MGACBAM_F16 = 1, MGACBAM_BF16 = 2 };
@@ -118,6 +118,7 @@ typedef struct mgacbam_ctx_layout {
   int64_t cidx;     /* (B,HW)   int32: first arg-max channel of u          masked_cbam.py:135 */
   int64_t sa;       /* (B,HW)   spatial gate                              masked_cbam.py:147 */
   int64_t proj;     /* (B,hid,HW) W1-projection of x, only when hid <= MGACBAM_PROJ_MAX_HIDDEN (else empty)  */
+  int64_t sync;     /* int32: (B, ceil(HW/16)+1) tile generation flags of MGACBAM_FWD_FUSE (see there), 4 status words, (B) ca flags */
   int64_t total;    /* == mgacbam_ctx_bytes()                                                 */
 } mgacbam_ctx_layout_t;
 
@@ -143,7 +144,17 @@ enum {
   MGACBAM_FWD_POOL = 1,      /* k_pool : masked avg/max pooling over H*W                      reads x           */
   MGACBAM_FWD_CHAN = 2,      /* k_chan : shared MLP + channel gate (prologue), channel max/mean planes  reads x */
   MGACBAM_FWD_APPLY = 4,     /* k_apply: k x k conv + spatial gate (prologue), y = x + alpha (x ca sa - x)      */
-  MGACBAM_FWD_ALL = 7
+  MGACBAM_FWD_ALL = 7,
+  MGACBAM_FWD_FUSE = 8       /* CHAN + APPLY as ONE launch (k_gate) that reads x once instead of twice: every workgroup keeps
+                                its tile of x (all channels) in registers and hands its plane rows to the neighbouring
+                                tiles through generation flags; one role workgroup per sample runs the shared MLP.
+                                CONTRACT: the caller zero-fills ctx[sync .. total) once after allocating ctx (and again
+                                after a call that was aborted mid-flight); the library keeps that state consistent.
+                                Levels whose shape is not eligible (C > 4096, tiles under 16 px, very wide k x k halos)
+                                run as three launches as without the flag.  Waits are bounded: a hand-off that times
+                                out (never expected -- a consumer only waits for workgroups a few ids away, dispatched
+                                before or with it) sets status word 0 (int32 at ctx[sync + 4*B*(ceil(HW/16)+1)]) and the
+                                launch still drains; tests assert it stays 0                                           */
 };
 enum {
   MGACBAM_BWD_REDUCE1 = 1,    /* k_bwd_reduce1: sums of gy*x over H*W and over C                reads x, gy       */

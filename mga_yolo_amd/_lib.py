@@ -8,7 +8,7 @@ import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGACBAM_LIB") or os.path.join(_PKG, "libmgacbam.so")   # MGACBAM_LIB: A/B builds in tuning sweeps
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_LEVELS = 8
 F32, F16, BF16 = 0, 1, 2
 # stage bit masks (include/mgacbam.h)
@@ -17,6 +17,7 @@ BWD_STAGES = dict(reduce1=1, convT=2, reduce2=4, wsa=8, params=16, apply=32)
 BWD_FUSE = 64
 FWD_SAVE_PROJ, BWD_HAVE_PROJ, PROJ_MAX_HIDDEN = 1, 1, 4
 FWD_ALL, BWD_PARAMS, BWD_INPUTS, BWD_ALL = 7, 31, 32, 127
+FWD_FUSE = 8   # with FWD_ALL: one launch, in-launch hand-off through ctx.sync (caller zero-fills it once)
 
 _c_float_p = C.POINTER(C.c_float)
 
@@ -59,7 +60,7 @@ class EcaBwdLevel(C.Structure):                  # mgacbam_eca_bwd_level_t
                 ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dtype", C.c_int32)]
 
 
-CTX_FIELDS = ("S", "use", "den", "avg", "mx", "mavg", "valid", "amax", "h_avg", "h_mx", "ca", "planes", "cidx", "sa", "proj", "total")
+CTX_FIELDS = ("S", "use", "den", "avg", "mx", "mavg", "valid", "amax", "h_avg", "h_mx", "ca", "planes", "cidx", "sa", "proj", "sync", "total")
 
 
 class CtxLayout(C.Structure):                    # mgacbam_ctx_layout_t
@@ -157,6 +158,10 @@ def scratch_bytes(B, Cc, H, W, hidden, k) -> int:
 
 
 def ctx_layout(B, Cc, H, W, hidden) -> dict:
-    L = CtxLayout()
-    check(load().mgacbam_ctx_layout(B, Cc, H, W, hidden, C.byref(L)), "mgacbam_ctx_layout")
-    return {n: getattr(L, n) for n in CTX_FIELDS}
+    key = ("layout", B, Cc, H, W, hidden)
+    lay = _size_cache.get(key)
+    if lay is None:
+        L = CtxLayout()
+        check(load().mgacbam_ctx_layout(B, Cc, H, W, hidden, C.byref(L)), "mgacbam_ctx_layout")
+        lay = _size_cache[key] = {n: getattr(L, n) for n in CTX_FIELDS}
+    return dict(lay)

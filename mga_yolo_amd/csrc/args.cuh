@@ -13,6 +13,8 @@ struct Geo {
   int proj_h;      // > 0: W1-projection planes of x are saved (forward) / available (backward); = hidden (<= kProjMax)
 };
 constexpr int kProjMax = 4;   // MGACBAM_PROJ_MAX_HIDDEN
+constexpr int kGateR = 16;    // channels a thread of the x-resident kernels keeps in registers (x VEC pixels each)
+constexpr int kSyncPx = 16;   // a hand-off tile is at least this many pixels: ctx.sync holds ceil(HW/kSyncPx)+1 flags per sample
 
 // saved statistics (device pointers into the caller's ctx buffer) -- see mgacbam_ctx_layout_t
 struct CtxPtrs {
@@ -22,6 +24,7 @@ struct CtxPtrs {
   float* h_avg; float* h_mx; float* ca;
   float* planes; int* cidx; float* sa;
   float* proj;     // (B, hidden, HW) when hidden <= kProjMax
+  int* sync;       // in-launch hand-off state: [B][nflag] tile generation flags, 4 status words ([0] = time-out), [B] per-sample ca generation flags
 };
 
 struct ParamPtrs { const float* w1; const float* b1; const float* w2; const float* b2; const float* wsa; const float* beta; };
@@ -36,11 +39,16 @@ struct Tune {
   int wsa_th;      // k_bwd_wsa tiles: fewer rows so 4 staged planes stay under ~16 KB of LDS (role workgroups)
   int apply_rows;  // k_apply: upper bound of the plane rows (tile rows + halo) staged per workgroup
   int nt_stores;   // 1: y / gx are written with non-temporal stores
+  int gate_rows;   // k_gate: upper bound of the plane rows (tile rows + halo) staged per workgroup
+  int gate_tx;     // k_gate (x-resident chan+apply): TX lanes along H*W, TY = 256/TX slices of kGateR channels each; 0 = not eligible
 };
 
 struct FwdArgs {
   const void* x; const float* mask; void* y;
   CtxPtrs c; ParamPtrs p; Geo g; Tune t;
+  int nflag;       // flags per sample in c.sync (host: sync_flags(HW))
+  int fused;       // MGACBAM_FWD_FUSE path selected for this level's group
+  long long* trace;   // MGACBAM_TRACE builds only: per-workgroup phase timestamps (tools/trace_gate.py), else nullptr
 };
 
 // transient backward buffers (device pointers into the caller's scratch buffer)

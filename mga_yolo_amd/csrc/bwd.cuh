@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_convT(const Group<BwdArgs> G) {
   float* tg = smem + ((3 * k * k + 3) & ~3);   // g_pre tile + halo
   for (int i = tid; i < 3 * k * k; i += kBlock) wts[i] = A.p.wsa[i];
   const float* gpre = A.s.gpre + static_cast<size_t>(c.b) * g.HW;
-  stage_window<8>(tg, 1, c.PH, c.PW, c.y0 - c.pad, c.x0 - c.pad, g, [&](int) { return gpre; });
+  stage_window<8>(tg, 1, c.PH, c.PW, c.y0 - c.pad, c.x0 - c.pad, g, [&](int, int off) { return gpre[off]; });
   __syncthreads();
   const int TWQ = A.t.conv_twq;
   const int py = tid / TWQ, q = tid - py * TWQ;
@@ -214,7 +214,7 @@ __device__ __forceinline__ void bwd_wsa_body(const BwdArgs& A, const int local, 
   const float* gpre = A.s.gpre + static_cast<size_t>(c.b) * g.HW;
   const float* pl = A.c.planes + static_cast<size_t>(c.b) * 3 * g.HW;
   stage_window<8>(tg, 4, c.PH, c.PW, c.y0 - c.pad, c.x0 - c.pad, g,
-                   [&](int p) { return p == 0 ? gpre : pl + static_cast<size_t>(p - 1) * g.HW; });
+                   [&](int p, int off) { return p == 0 ? gpre[off] : pl[static_cast<size_t>(p - 1) * g.HW + off]; });
   __syncthreads();
   constexpr int KK = K ? K : 1;
   const int nout = 3 * k * k;

@@ -188,6 +188,52 @@ __device__ __forceinline__ bool xcd_sample_part(int bid, int B, int P, int& b, i
   return b < B;
 }
 
+// ---------------------------------------------------------------------------------------------
+// In-launch hand-off between workgroups (cdna_hip_programming.md Guideline 16), used by the x-resident kernels: a
+// workgroup publishes a few hundred bytes (its plane rows, its partial sums) that OTHER workgroups of the same launch
+// consume.  The handed-off words themselves are written and read with relaxed AGENT-scope atomics (sc1 accesses: written
+// through / fetched past the non-coherent caches), so no whole-cache release/acquire is needed -- measured: an agent
+// release+acquire pair per workgroup (buffer_wbl2 + buffer_inv) made a 80 us forward 220 us.
+//   producer:  st_agent(...) -> EVERY wave s_waitcnt vmcnt(0) -> barrier -> one lane bumps the flag (relaxed agent add)
+//   consumer:  lanes poll the flags (relaxed agent loads, s_sleep) -> s_waitcnt -> barrier -> ld_agent(...) of the data
+// Flags are generation counters: every workgroup bumps its own flag exactly once per call, so after call n a flag reads n;
+// nothing is reset (the region is zero-filled once by the caller) and graph replay needs no per-launch argument.
+// Every spin is bounded: on time-out the error word is set and the workgroup carries on, so the launch always drains.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// all of this workgroup's st_agent stores are complete -> bump its flag (fire and forget: the generation this call will
+// reach is known beforehand, own flag + 1, read at the top of the kernel where its latency is hidden)
+__device__ __forceinline__ void handoff_publish(int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wait until flags[lo..hi] have all reached generation `gen`
+__device__ __forceinline__ void handoff_wait(const int* flags, int lo, int hi, int gen, int* err) {
+  for (int t = lo + static_cast<int>(threadIdx.x); t <= hi; t += kBlock) {
+    unsigned spins = 0;
+    while (ld_agent(flags + t) - gen < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1u << 20)) { st_agent(err, 1); break; }   // ~1 s: give up, flag it, let the launch drain
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// poor man's thread trace (builds with -DMGACBAM_TRACE, tools/trace_gate.py): thread 0 of a workgroup records the 100 MHz
+// wall clock at phase boundaries, slot 15 holds the hardware id (XCD / SE / CU)
+#ifdef MGACBAM_TRACE
+#define TRACE_MARK(buf, gid, slot) do { if ((buf) && threadIdx.x == 0) (buf)[static_cast<size_t>(gid) * 16 + (slot)] = static_cast<long long>(wall_clock64()); } while (0)
+#define TRACE_HWID(buf, gid) do { if ((buf) && threadIdx.x == 0) { unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); (buf)[static_cast<size_t>(gid) * 16 + 15] = (static_cast<long long>(xcc) << 32) | hw; } } while (0)
+#else
+#define TRACE_MARK(buf, gid, slot) do {} while (0)
+#define TRACE_HWID(buf, gid) do {} while (0)
+#endif
+
 // level of a grouped launch that owns workgroup `bid`; returns the id relative to that level in `local`
 template <typename G>
 __device__ __forceinline__ int find_level(const G& g, int bid, int& local) {

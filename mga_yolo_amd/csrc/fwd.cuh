@@ -357,10 +357,10 @@ __global__ __launch_bounds__(kBlock) void k_chan(const Group<FwdArgs> G) {
 // LDS staging of image planes with zero padding.  Loads are issued U at a time per thread before any LDS store,
 // so a tile costs one or two global-load latencies, not one per element.
 //   generic form: `total` elements, element idx -> (plane p, row yy, col xx) of a PH x PW window whose top-left
-//   image coordinate is (ya, xa); src(p) -> pointer to plane p of this sample (H*W floats)
+//   image coordinate is (ya, xa); load(p, off) -> element `off` of plane p of this sample (H*W floats)
 // ---------------------------------------------------------------------------------------------
-template <int U, typename SrcFn>
-__device__ __forceinline__ void stage_window(float* tile, int NP, int PH, int PW, int ya, int xa, const Geo& g, SrcFn src) {
+template <int U, typename LoadFn>
+__device__ __forceinline__ void stage_window(float* tile, int NP, int PH, int PW, int ya, int xa, const Geo& g, LoadFn load) {
   const int total = NP * PH * PW;
   // idx / d == umulhi(idx, 2^32/d + 1) for idx < 2^16; d == 1 would overflow the magic, so it gets the identity
   const unsigned mpw = PW > 1 ? 0xFFFFFFFFu / static_cast<unsigned>(PW) + 1u : 0u;
@@ -376,7 +376,7 @@ __device__ __forceinline__ void stage_window(float* tile, int NP, int PH, int PW
       const int yy = static_cast<int>(r) - static_cast<int>(p) * PH;
       const int gy_ = ya + yy, gx_ = xa + xx;
       v[u] = 0.f;
-      if (idx < total && gy_ >= 0 && gy_ < g.H && gx_ >= 0 && gx_ < g.W) v[u] = src(static_cast<int>(p))[gy_ * g.W + gx_];
+      if (idx < total && gy_ >= 0 && gy_ < g.H && gx_ >= 0 && gx_ < g.W) v[u] = load(static_cast<int>(p), gy_ * g.W + gx_);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -448,7 +448,7 @@ __device__ __forceinline__ void apply_body(const FwdArgs& A, const int bid, floa
   for (int t = tid; t < 3 * k * k; t += kBlock) wts[t] = A.p.wsa[t];
   for (int c = tid; c < g.C; c += kBlock) s_ca[c] = cab[c];
   const float* pl = A.c.planes + static_cast<size_t>(b) * 3 * g.HW;
-  stage_window<12>(planes, 3, PH, PW, r0 - pad, -pad, g, [&](int p) { return pl + static_cast<size_t>(p) * g.HW; });
+  stage_window<12>(planes, 3, PH, PW, r0 - pad, -pad, g, [&](int p, int off) { return pl[static_cast<size_t>(p) * g.HW + off]; });
   __syncthreads();
   for (int tp = tid; tp < TP; tp += kBlock) {                  // one pixel per thread (TP <= 512)
     if (p0 + tp >= g.HW) break;
@@ -517,6 +517,247 @@ __global__ __launch_bounds__(kBlock) void k_apply(const Group<FwdArgs> G) {
   int local;
   const int l = find_level(G, blockIdx.x, local);
   apply_body<T, VEC, K>(G.lv[l], local, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gate: k_chan + k_apply in ONE pass over x with the tile RESIDENT IN REGISTERS (MGACBAM_FWD_FUSE).
+//   workgroup = (sample b, tile of TX vectors = TP contiguous pixels) x ALL channels: thread (tx, ty) keeps channels
+//   ty, ty+TY, ... (kGateR of them) of its VEC pixels in registers -- 64 KB of x per workgroup, read from HBM once.
+//     1. issue the loads; meanwhile the sample's MLP -> ca in LDS (k_chan's prologue)
+//     2. per pixel max_c / mean_c of x*ca (LDS combine over the TY slices) -> planes, cidx to ctx (backward needs them anyway)
+//     3. publish the tile's plane rows; wait for the tiles whose rows the k x k window of this tile touches (in-launch
+//        hand-off, common.cuh).  Consumers only ever wait on tiles at most `span` tile-ids away and workgroups are
+//        dispatched in id order, so the producers are resident or done; the host only selects this kernel when 8*span
+//        workgroups fit on the chip many times over, and every wait is bounded anyway.
+//     4. conv + sigmoid -> sa (k_apply's prologue), y = x + alpha (x ca sa - x) straight from the registers.
+//   HBM traffic: x once + y once (2E) instead of k_chan + k_apply's 3E.
+//   LDS: [2C scratch][2h][C ca] then max(3*256*VEC combine, [3*k*k weights][3*rows*(W+k-1) planes][TP sa])
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC, int K>
+__device__ __forceinline__ void gate_body(const FwdArgs& A, const int bid, float* smem) {
+  constexpr int R = kGateR;
+  const Geo& g = A.g;
+  const int tid = threadIdx.x;
+  const int TX = A.t.gate_tx, lt = ilog2(TX);
+  const int tx = tid & (TX - 1), ty = tid >> lt, TY = kBlock >> lt;
+  const int nv = g.HW / VEC;
+  const int ntile = (nv + TX - 1) / TX;
+  int b, tile;
+  if (!xcd_sample_part(bid, g.B, ntile, b, tile)) return;
+  const int i = tile * TX + tx;
+  const bool active = i < nv;
+  const int ii = active ? i : nv - 1;
+  const size_t base = static_cast<size_t>(b) * g.C * g.HW + static_cast<size_t>(ii) * VEC;
+  const T* xp = static_cast<const T*>(A.x) + base;
+  T* yp = static_cast<T*>(A.y) + base;
+
+  const int gid = blockIdx.x;
+  TRACE_HWID(A.trace, gid);
+  TRACE_MARK(A.trace, gid, 0);                                 // start
+  float xr[R][VEC];                                            // the resident tile
+#pragma unroll
+  for (int j = 0; j < R; ++j) load_vec<T, VEC>(xp + static_cast<size_t>(min(ty + j * TY, g.C - 1)) * g.HW, xr[j]);
+  int* flags = A.c.sync + static_cast<size_t>(b) * A.nflag;
+  const int gen = ld_agent(flags + tile) + 1;                  // the generation this call brings every flag of the level to
+
+  float* s_ca = smem;
+  float* work = s_ca + ((g.C + 3) & ~3);
+  {                                                            // ca of this sample: from its role workgroup (gate_role)
+    int* caflag = A.c.sync + static_cast<size_t>(g.B) * A.nflag + 4;
+    handoff_wait(caflag, b, b, gen, caflag - 4);
+    const float* cab = A.c.ca + static_cast<size_t>(b) * g.C;
+    TRACE_MARK(A.trace, gid, 1);                               // ca flag seen
+    for (int c = tid; c < g.C; c += kBlock) s_ca[c] = ld_agent(cab + c);
+    __syncthreads();
+  }
+  TRACE_MARK(A.trace, gid, 2);                                 // ca in LDS
+
+  // ---- 2. channel max / mean planes of this tile ---------------------------------------------------------------
+  float vmax[VEC], vsum[VEC];
+  int vidx[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { vmax[e] = -INFINITY; vsum[e] = 0.f; vidx[e] = ty; }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int c = ty + j * TY;
+    if (c < g.C) {
+      const float cac = s_ca[c];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float uu = xr[j][e] * cac;                       // masked_cbam.py:130
+        vsum[e] += uu;
+        if (uu > vmax[e]) { vmax[e] = uu; vidx[e] = c; }
+      }
+    }
+  }
+  TRACE_MARK(A.trace, gid, 3);                                 // x arrived, per-thread channel scan done
+  {
+    float* smax = work;
+    int* sidx = reinterpret_cast<int*>(work + kBlock * VEC);
+    float* ssum = work + 2 * kBlock * VEC;
+    if (ty > 0) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { smax[tid * VEC + e] = vmax[e]; sidx[tid * VEC + e] = vidx[e]; ssum[tid * VEC + e] = vsum[e]; }
+    }
+    __syncthreads();
+    if (ty == 0 && active) {
+      for (int r = 1; r < TY; ++r) {
+        const int o = (r * TX + tx) * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          argmax_combine(vmax[e], vidx[e], smax[o + e], sidx[o + e]);
+          vsum[e] += ssum[o + e];
+        }
+      }
+      float* pl = A.c.planes + static_cast<size_t>(b) * 3 * g.HW + static_cast<size_t>(i) * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        st_agent(pl + e, vmax[e]);
+        st_agent(pl + g.HW + e, vsum[e] / static_cast<float>(g.C));   // masked_cbam.py:136
+      }
+      store_ivec<VEC>(A.c.cidx + static_cast<size_t>(b) * g.HW + static_cast<size_t>(i) * VEC, vidx);
+    }
+  }
+
+  // ---- 3. hand the plane rows over ------------------------------------------------------------------------------
+  const int k = K ? K : g.k, pad = k / 2;
+  const int TP = TX * VEC;
+  const int p0 = tile * TP;                                     // first pixel of the tile
+  const int p1 = min(p0 + TP, g.HW) - 1;                        // last pixel
+  const int r0 = p0 / g.W, r1 = p1 / g.W;
+  const int PW = g.W + k - 1, PH = (r1 - r0 + 1) + k - 1;
+  TRACE_MARK(A.trace, gid, 4);                                 // planes stored (not yet complete)
+  handoff_publish(flags + tile);                               // (its barrier also frees the combine area)
+  TRACE_MARK(A.trace, gid, 5);                                 // published
+  float* wts = work;
+  float* planes = work + ((3 * k * k + 3) & ~3);
+  float* s_sa = planes + 3 * A.t.gate_rows * PW;                // gate_rows >= PH (host-computed bound)
+  for (int t = tid; t < 3 * k * k; t += kBlock) wts[t] = A.p.wsa[t];
+  {
+    const int ra = max(r0 - pad, 0), rb = min(r1 + pad, g.H - 1);
+    handoff_wait(flags, (ra * g.W) / TP, ((rb + 1) * g.W - 1) / TP, gen, A.c.sync + static_cast<size_t>(g.B) * A.nflag);
+  }
+  TRACE_MARK(A.trace, gid, 6);                                 // neighbours' rows are there
+  const float* pl = A.c.planes + static_cast<size_t>(b) * 3 * g.HW;
+  stage_window<12>(planes, 3, PH, PW, r0 - pad, -pad, g, [&](int p, int off) {
+    const float* q = pl + static_cast<size_t>(p) * g.HW + off;
+    return p < 2 ? ld_agent(q) : *q;                       // plane 2 = sigma(mask), written by k_pool (previous launch)
+  });
+  __syncthreads();
+  TRACE_MARK(A.trace, gid, 7);                                 // window staged
+
+  // ---- 4. spatial gate of the tile, then y from the registers ----------------------------------------------------
+  // (a register-tiled form -- wave = plane, lane = 4 adjacent pixels, ~5x fewer LDS instructions -- was measured: the conv
+  //  phase went 2.2 -> 1.7 us per round, the launch did not move, 27 more VGPRs; not kept)
+  for (int tp = tid; tp < TP; tp += kBlock) {
+    if (p0 + tp >= g.HW) break;
+    const int p = p0 + tp;
+    const int py = p / g.W, px = p - py * g.W;
+    const float* origin = planes + (py - r0) * PW + px;
+    float acc = 0.f;
+    if (K) {
+      constexpr int KK = K ? K : 1;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int ti = 0; ti < KK; ++ti) {
+          const float* row = origin + q * PH * PW + ti * PW;
+          const float* wr = wts + (q * KK + ti) * KK;
+#pragma unroll
+          for (int tj = 0; tj < KK; ++tj) acc += wr[tj] * row[tj];
+        }
+      }
+    } else {
+      for (int q = 0; q < 3; ++q)
+        for (int ti = 0; ti < k; ++ti) {
+          const float* row = origin + q * PH * PW + ti * PW;
+          const float* wr = wts + (q * k + ti) * k;
+          for (int tj = 0; tj < k; ++tj) acc += wr[tj] * row[tj];
+        }
+    }
+    const float sa = sigmoidf_(acc);                            // masked_cbam.py:147
+    s_sa[tp] = sa;
+    A.c.sa[static_cast<size_t>(b) * g.HW + p] = sa;
+  }
+  __syncthreads();
+  TRACE_MARK(A.trace, gid, 8);                                 // conv done
+#ifndef MGACBAM_TRACE
+  if (!active) return;
+#endif
+  float sav[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) sav[e] = active ? s_sa[tx * VEC + e] : 0.f;
+  const float a = softplusf_(*A.p.beta);                        // masked_cbam.py:150-152
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int c = ty + j * TY;
+    if (c < g.C) {
+      const float cac = s_ca[c];
+      float yv[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float u = xr[j][e] * cac;                         // masked_cbam.py:130
+        yv[e] = xr[j][e] + a * (u * sav[e] - xr[j][e]);         // masked_cbam.py:148,171
+      }
+      if (active) store_vec_stream<T, VEC>(yp + static_cast<size_t>(c) * g.HW, yv, A.t.nt_stores);
+    }
+  }
+#ifdef MGACBAM_TRACE
+  TRACE_MARK(A.trace, gid, 9);                                 // stores issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  TRACE_MARK(A.trace, gid, 10);                                // stores complete
+#endif
+}
+
+// role workgroup of k_gate (one per sample, lowest ids of the launch): the shared MLP, once per sample instead of once per
+// tile -- as a prologue of every tile workgroup its three dependent phases cost 8.7 us per step (ablation), as the tail of
+// k_pool's last arriver 9.4 us; here it runs while the tile workgroups' x loads are in flight.
+__device__ __forceinline__ void gate_role(const FwdArgs& A, const int b, float* smem) {
+  const Geo& g = A.g;
+  const int tid = threadIdx.x;
+  float* s_in = smem;
+  float* s_h = smem + 2 * g.C;
+  float* s_ca = s_h + 2 * g.hidden;
+  int* caflag = A.c.sync + static_cast<size_t>(g.B) * A.nflag + 4 + b;
+  TRACE_MARK(A.trace, blockIdx.x, 0);
+  mlp_gate_to_lds(A, b, false, s_in, s_h, s_ca);
+  TRACE_MARK(A.trace, blockIdx.x, 3);
+  for (int c = tid; c < g.C; c += kBlock) st_agent(A.c.ca + static_cast<size_t>(b) * g.C + c, s_ca[c]);
+  for (int j = tid; j < g.hidden; j += kBlock) {
+    A.c.h_avg[static_cast<size_t>(b) * g.hidden + j] = s_h[j];
+    A.c.h_mx[static_cast<size_t>(b) * g.hidden + j] = s_h[g.hidden + j];
+  }
+  handoff_publish(caflag);
+  TRACE_MARK(A.trace, blockIdx.x, 5);
+}
+
+struct GateGroup {
+  Group<FwdArgs> g;
+  int nrole;                     // role workgroups = sum of the levels' batch sizes; tile workgroup ids follow
+  int rstart[kGroupMax + 1];     // level l owns role ids [rstart[l], rstart[l+1])
+};
+
+#ifdef MGACBAM_GATE_WAVES
+#define GATE_OCC __attribute__((amdgpu_waves_per_eu(MGACBAM_GATE_WAVES)))
+#else
+#define GATE_OCC
+#endif
+template <typename T, int VEC, int K>
+__global__ __launch_bounds__(kBlock) GATE_OCC void k_gate(const GateGroup GG) {
+  extern __shared__ __align__(16) float smem[];
+  const int bid = blockIdx.x;
+  if (bid < GG.nrole) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < kGroupMax; ++i)
+      if (i < GG.g.n && bid >= GG.rstart[i]) l = i;
+    gate_role(GG.g.lv[l], bid - GG.rstart[l], smem);
+    return;
+  }
+  int local;
+  const int l = find_level(GG.g, bid - GG.nrole, local);
+  gate_body<T, VEC, K>(GG.g.lv[l], local, smem);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -54,6 +54,9 @@ static int check_shape(int B, int C, int H, int W, int hidden, int k) {
   return 0;
 }
 
+// hand-off flags per sample: one per tile of >= kSyncPx pixels, whatever tile size the launch geometry picks
+static size_t sync_flags(size_t HW) { return (HW + kSyncPx - 1) / kSyncPx + 1; }
+
 static void ctx_layout(int B, int C, int H, int W, int hidden, mgacbam_ctx_layout_t* L) {
   const size_t HW = static_cast<size_t>(H) * W;
   size_t o = 0;
@@ -67,6 +70,7 @@ static void ctx_layout(int B, int C, int H, int W, int hidden, mgacbam_ctx_layou
   L->cidx = take(static_cast<size_t>(B) * HW);
   L->sa = take(static_cast<size_t>(B) * HW);
   L->proj = take(hidden <= MGACBAM_PROJ_MAX_HIDDEN ? static_cast<size_t>(B) * hidden * HW : 0);
+  L->sync = take(static_cast<size_t>(B) * sync_flags(HW) + 4 + B);
   L->total = static_cast<int64_t>(o);
 }
 
@@ -82,6 +86,7 @@ static CtxPtrs ctx_ptrs(void* base, int B, int C, int H, int W, int hidden) {
   c.ca = reinterpret_cast<float*>(p + L.ca);
   c.planes = reinterpret_cast<float*>(p + L.planes); c.cidx = reinterpret_cast<int*>(p + L.cidx); c.sa = reinterpret_cast<float*>(p + L.sa);
   c.proj = reinterpret_cast<float*>(p + L.proj);
+  c.sync = reinterpret_cast<int*>(p + L.sync);
   return c;
 }
 
@@ -146,6 +151,21 @@ static Tune choose_tune(int B, int C, int H, int W, int k, int dtype = MGACBAM_F
   if (rows > H) rows = H;
   t.apply_rows = rows + k - 1;
   t.nt_stores = env_int("MGACBAM_NT", 1) ? 1 : 0;
+  // k_gate (x-resident chan+apply): every thread keeps kGateR channels, so TY = ceil(C / kGateR) slices (power of two) and the
+  // rest of the 256 threads go along H*W.  Eligible when a tile is >= kSyncPx pixels (ctx.sync has one flag per kSyncPx),
+  // the tiles a k x k window reaches are few (their workgroups must be co-resident: 8 ids apart per tile, common.cuh) and
+  // the staged rows fit in LDS; otherwise the three-launch forward runs.
+  t.gate_tx = 0; t.gate_rows = 0;
+  const int gty = pow2_ceil((C + kGateR - 1) / kGateR);
+  if (gty <= kBlock && env_int("MGACBAM_GATE", 1)) {
+    const int gtx = kBlock / gty, TP = gtx * VEC;
+    int grows = (TP - 1) / W + 2;
+    if (grows > H) grows = H;
+    grows += k - 1;
+    const int span = ((k / 2) * W + TP - 1) / TP + 1;           // tiles reached on either side
+    const size_t lds = (3 * static_cast<size_t>(grows) * (W + k - 1) + TP + 3 * k * k + 3 * C + 64) * sizeof(float);
+    if (TP >= kSyncPx && 8 * span <= 256 && lds <= 48 * 1024) { t.gate_tx = gtx; t.gate_rows = grows; }
+  }
   return t;
 }
 
@@ -279,6 +299,16 @@ static size_t chan_smem(const Geo& g, int vec, bool proj) {
 static size_t apply_smem(const Geo& g, const Tune& t, int vec) {
   return (((3 * g.k * g.k + 3) & ~3) + 3 * static_cast<size_t>(t.apply_rows) * (g.W + g.k - 1) + t.chan_tx * vec + g.C) * sizeof(float);
 }
+static size_t gate_smem(const Geo& g, const Tune& t, int vec) {
+  const size_t head = (g.C + 3) & ~3;
+  const size_t role = 3 * static_cast<size_t>(g.C) + 2 * g.hidden;           // gate_role: the MLP's scratch
+  const size_t conv = ((3 * g.k * g.k + 3) & ~3) + 3 * static_cast<size_t>(t.gate_rows) * (g.W + g.k - 1) + static_cast<size_t>(t.gate_tx) * vec;
+  return std::max(role, head + std::max(conv, static_cast<size_t>(3) * kBlock * vec)) * sizeof(float);
+}
+static int gate_tiles(const Tune& t, int H, int W, int vec) {
+  const int nv = H * W / vec;
+  return (nv + t.gate_tx - 1) / t.gate_tx;
+}
 static size_t bwd_apply_smem(const Geo& g, int vec) { return (5 * static_cast<size_t>(g.C) + 2 * g.hidden + kBlock * vec) * sizeof(float); }
 static size_t reduce1_smem(const Geo& g, int vec) { return (3 * static_cast<size_t>(g.C) + kBlock * vec) * sizeof(float); }
 
@@ -294,7 +324,9 @@ static int forward_args(const mgacbam_fwd_level_t& L, FwdArgs& A, Sig& sig) {
   const size_t need = VEC * elem_size(L.dtype);
   if (!aligned_to(L.x, need) || !aligned_to(L.y, need) || !aligned_to(L.ctx, 16) || (L.mask && !aligned_to(L.mask, 16)))
     return fail(MGACBAM_E_ALIGN, "forward: x/y must be %zu-byte aligned, ctx 16-byte, mask %d-byte", need, VEC * 4);
-  A.x = L.x; A.mask = L.mask; A.y = L.y;
+  A.x = L.x; A.mask = L.mask; A.y = L.y; A.fused = 0;
+  { const char* tp = getenv("MGACBAM_TRACE_PTR"); A.trace = (tp && *tp) ? reinterpret_cast<long long*>(strtoull(tp, nullptr, 0)) : nullptr; }
+  A.nflag = static_cast<int>(sync_flags(static_cast<size_t>(L.H) * L.W));
   A.c = ctx_ptrs(L.ctx, L.B, L.C, L.H, L.W, L.p.hidden);
   A.p = make_params(L.p);
   A.g = make_geo(L.B, L.C, L.H, L.W, L.p);
@@ -312,6 +344,11 @@ static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStre
   for (int l = 0; l < n; ++l) { lv[l].t.pool_cpt = pool_cpt; G.lv[l] = lv[l]; }
   auto fill = [&](auto blocks_of) { int tot = 0; for (int l = 0; l < n; ++l) { G.start[l] = tot; tot += blocks_of(lv[l]); } G.start[n] = tot; return tot; };
 
+  // MGACBAM_FWD_FUSE: stages 2 + 3 become ONE x-resident launch (k_gate) when every level of the group is eligible
+  bool gate = (stages & MGACBAM_FWD_FUSE) && (stages & MGACBAM_FWD_CHAN) && (stages & MGACBAM_FWD_APPLY) && !sig.proj && sig.vec <= 4;
+  for (int l = 0; l < n && gate; ++l) gate = lv[l].t.gate_tx > 0;
+  if (gate) for (int l = 0; l < n; ++l) { lv[l].fused = 1; G.lv[l].fused = 1; }
+
   if (stages & MGACBAM_FWD_POOL) {  // 1. pooling
     const int grid = fill([&](const FwdArgs& a) { return sweep_blocks(a, a.t.pool_tx, pool_cpt); });
 #define CALL_POOL2(CPTV) if (sig.has_mask) LAUNCH((k_pool<TT, VV, CPTV, true>), grid, 0, st, G); else LAUNCH((k_pool<TT, VV, CPTV, false>), grid, 0, st, G)
@@ -320,6 +357,21 @@ static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStre
 #undef CALL_POOL
 #undef CALL_POOL2
     if (int e = launch_status("k_pool")) return e;
+  }
+  if (gate) {
+    size_t smem = 0;
+    for (int l = 0; l < n; ++l) smem = std::max(smem, gate_smem(lv[l].g, lv[l].t, sig.vec));
+    GateGroup GG;
+    const int tiles = fill([&](const FwdArgs& a) { return xcd_grid(a.g.B, gate_tiles(a.t, a.g.H, a.g.W, sig.vec)); });
+    GG.g = G;
+    GG.nrole = 0;
+    for (int l = 0; l < n; ++l) { GG.rstart[l] = GG.nrole; GG.nrole += lv[l].g.B; }
+    GG.rstart[n] = GG.nrole;
+    const int grid = GG.nrole + tiles;
+#define CALL_GATE(Tt, Vv) if (sig.k == 7) LAUNCH((k_gate<Tt, Vv, 7>), grid, smem, st, GG); else LAUNCH((k_gate<Tt, Vv, 0>), grid, smem, st, GG)
+    DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_GATE);
+#undef CALL_GATE
+    return launch_status("k_gate");
   }
   if (stages & MGACBAM_FWD_CHAN) {  // 2. shared MLP + channel gate (prologue), channel max / mean planes
     size_t smem = 0;

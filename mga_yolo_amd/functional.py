@@ -31,6 +31,8 @@ class BlockConfig:
 
 _DTYPES = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
 _USE_PROJ = bool(int(os.environ.get("MGACBAM_PROJ", "0")))
+# k_chan + k_apply as ONE x-resident launch (k_gate, MGACBAM_FWD_FUSE); MGACBAM_FUSE_FWD=0 restores the three-launch forward
+_FUSE_FWD = bool(int(os.environ.get("MGACBAM_FUSE_FWD", "1")))
 SLOTS = 8  # tensors per level in the flat argument list: x, mask, w1, b1, w2, b2, wsa, beta
 
 
@@ -106,6 +108,8 @@ class _PyramidFn(torch.autograd.Function):
             pc = [_ready(p) for p in params]
             y = torch.empty_like(xc)
             cbuf = torch.empty(_lib.ctx_bytes(B, Cc, H, W, cfg.hidden), dtype=torch.uint8, device=dev)
+            if _FUSE_FWD:       # FWD_FUSE contract: the hand-off flags at the end of ctx start at zero
+                cbuf[_lib.ctx_layout(B, Cc, H, W, cfg.hidden)["sync"]:].zero_()
             L = levels[l]
             L.x, L.mask, L.y, L.ctx = xc.data_ptr(), (None if m32 is None else m32.data_ptr()), y.data_ptr(), cbuf.data_ptr()
             L.p = _params_struct(pc, cfg)
@@ -118,7 +122,8 @@ class _PyramidFn(torch.autograd.Function):
             outs.append(y)
             meta.append(((None if mask is None else (mask.dtype, tuple(mask.shape))), proj))
         with torch.cuda.device(dev):
-            _lib.check(lib.mgacbam_forward(levels, n, torch.cuda.current_stream(dev).cuda_stream), "mgacbam_forward")
+            stages = _lib.FWD_ALL | (_lib.FWD_FUSE if _FUSE_FWD else 0)
+            _lib.check(lib.mgacbam_forward_stages(levels, n, stages, torch.cuda.current_stream(dev).cuda_stream), "mgacbam_forward_stages")
         ctx.save_for_backward(*keep)
         ctx.cfgs, ctx.meta = cfgs, meta
         return tuple(outs)
@@ -208,7 +213,9 @@ def ctx_views(cbuf: torch.Tensor, B, Cc, H, W, hidden) -> dict:
                   h_avg=(B, hidden), h_mx=(B, hidden), ca=(B, Cc), planes=(B, 3, HW), cidx=(B, HW), sa=(B, HW))
     if hidden <= _lib.PROJ_MAX_HIDDEN:
         shapes["proj"] = (B, hidden, HW)
-    ints = {"valid", "amax", "cidx"}
+    nflag = (HW + 15) // 16 + 1
+    shapes["sync"] = (B * nflag + 4 + B,)   # FWD_FUSE hand-off: (B, nflag) generation flags, [time-out flag, 3 spare], (B) arrival counters
+    ints = {"valid", "amax", "cidx", "sync"}
     out = {}
     for name, shp in shapes.items():
         n = 1

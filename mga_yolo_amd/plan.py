@@ -5,12 +5,14 @@ step are recorded once and replayed, instead of being issued from Python every s
 
 A ``PyramidPlan`` owns, per level: x, mask, y, gy, gx, gmask, ctx, scratch; and ONE flat fp32 bucket holding the parameter
 gradients of all levels (what data-parallel training all-reduces, see ``dp.py``).  ``forward`` / ``backward`` each make ONE
-library call on the current stream (7 kernel launches per step in total).  ``backward_params`` + ``backward_inputs`` is
+library call on the current stream (6 kernel launches per step in total).  ``backward_params`` + ``backward_inputs`` is
 the split form for callers that want the parameter gradients early (see ``dp.py``).
 """
 from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
+
+import os
 
 import torch
 
@@ -23,7 +25,10 @@ PARAM_NAMES = ("w1", "b1", "w2", "b2", "wsa", "beta")
 class PyramidPlan:
     def __init__(self, shapes: Sequence[Tuple[int, int, int, int]], params: Sequence[Sequence[torch.Tensor]],
                  cfgs: Sequence[BlockConfig], dtype: torch.dtype = torch.float32, device="cuda",
-                 with_mask: bool = True, want_gmask: bool = True, use_proj: bool = False):
+                 with_mask: bool = True, want_gmask: bool = True, use_proj: bool = False,
+                 fuse_forward: Optional[bool] = None):
+        # fuse_forward: k_chan + k_apply as ONE x-resident launch, k_gate (MGACBAM_FWD_FUSE); None = env MGACBAM_FUSE_FWD (on)
+        self.fuse_forward = bool(int(os.environ.get("MGACBAM_FUSE_FWD", "1"))) if fuse_forward is None else bool(fuse_forward)
         assert len(shapes) == len(params) == len(cfgs) and 1 <= len(shapes) <= _lib.MAX_LEVELS
         self.lib = _lib.load()
         self.device = torch.device(device)
@@ -68,6 +73,9 @@ class PyramidPlan:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def forward(self, stages: int = _lib.FWD_ALL):
+        both = _lib.FWD_STAGES["chan"] | _lib.FWD_STAGES["apply"]
+        if self.fuse_forward and (stages & both) == both:
+            stages |= _lib.FWD_FUSE     # ctx is zero-filled at allocation, as the flag's contract asks
         _lib.check(self.lib.mgacbam_forward_stages(self._fwd, self.n, stages, self._stream()), "mgacbam_forward_stages")
 
     def backward(self, stages: int = _lib.BWD_ALL):

@@ -325,6 +325,65 @@ def test_plan_executor_matches_oracle_with_and_without_projection_planes(F, want
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("shapes,with_mask", [
+    ([(4, 64, 16, 16), (4, 128, 8, 8), (4, 256, 4, 4)], True),
+    ([(32, 64, 80, 80), (32, 128, 40, 40), (32, 256, 20, 20)], True),      # BASELINE configs[1]: every CU busy, real waits
+    ([(3, 48, 17, 17), (5, 24, 9, 7)], True),                              # scalar (VEC=1) path, ragged, different B per level
+    ([(9, 64, 40, 40), (9, 64, 20, 20)], False),                           # no mask; B not a multiple of the 8 XCDs
+])
+def test_fused_forward_launch_equals_three_launches(F, shapes, with_mask):
+    """MGACBAM_FWD_FUSE: k_chan + k_apply as ONE x-resident launch (k_gate) with in-launch hand-off of the plane rows.
+    Outputs and saved ctx fields must match the three-launch forward (same arithmetic per element; only the order of the
+    channel-mean sum differs), the time-out word must stay clear and every tile flag must read the call count -- the
+    next call depends on it -- also under graph replay."""
+    from mga_yolo_amd.plan import PyramidPlan
+    params, cfgs = [], []
+    for l, (B, C, H, W) in enumerate(shapes):
+        p = O.Params.default_init(C, seed=l)
+        p.beta.fill_(0.3)
+        params.append((p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta))
+        cfgs.append(F.BlockConfig(hidden=p.w1.shape[0]))
+    plans = [PyramidPlan(shapes, params, cfgs, with_mask=with_mask, want_gmask=False, fuse_forward=f) for f in (False, True)]
+    gen = torch.Generator().manual_seed(7)
+    for l, (B, C, H, W) in enumerate(shapes):
+        x = torch.randn(B, C, H, W, generator=gen)
+        m = torch.randn(B, 1, H, W, generator=gen) * 2
+        m[0] = -40.0                                                        # sample 0: empty mask -> GAP fallback
+        for pl in plans:
+            pl.x[l].copy_(x)
+            if with_mask:
+                pl.mask[l].copy_(m)
+
+    def check(calls):
+        torch.cuda.synchronize()
+        for l, (B, C, H, W) in enumerate(shapes):
+            assert rel_err(plans[1].y[l], plans[0].y[l]) < 1e-6, (calls, l)
+            a, b = plans[0].ctx_view(l), plans[1].ctx_view(l)
+            for name in a:
+                if name in ("sync", "proj"):
+                    continue
+                if a[name].dtype == torch.int32:
+                    assert torch.equal(a[name], b[name]), (calls, l, name)
+                else:
+                    assert rel_err(b[name], a[name]) < 1e-6, (calls, l, name)
+            sync = b["sync"]
+            nf = B * ((H * W + 15) // 16 + 1)
+            assert int(sync[nf:nf + 4].abs().sum()) == 0, (calls, l, "hand-off timed out")
+            assert bool((sync[nf + 4:] == calls).all()), (calls, l, "per-sample ca flags")
+            flags = sync[:nf]
+            assert int(flags.max()) == calls and set(flags.unique().tolist()) <= {0, calls}, (calls, l)
+
+    plans[0].forward()
+    for rep in range(3):
+        plans[1].forward()
+        check(rep + 1)
+    g = plans[1].capture(plans[1].forward)          # capture warms up once (recording executes nothing)
+    for l in range(len(shapes)):
+        plans[1].y[l].zero_()
+    g.replay(); g.replay()
+    check(6)
+
+
 @pytest.mark.parametrize("k", [1, 9, 11, 15])
 def test_generic_spatial_kernel_sizes(F, k):
     """spatial_k other than 3/5/7 takes the run-time-k code paths of the conv prologue, transposed conv and dWsa kernels."""

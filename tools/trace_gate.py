@@ -1,0 +1,71 @@
+"""Poor man's thread trace of k_gate (needs a -DMGACBAM_TRACE build: python -c "from mga_yolo_amd import build;
+build.build(force=True, defines=['-DMGACBAM_TRACE'], out='mga_yolo_amd/libmgacbam_trace.so')", then run with
+MGACBAM_LIB=$PWD/mga_yolo_amd/libmgacbam_trace.so).  Thread 0 of every workgroup records the 100 MHz wall clock at phase
+boundaries; this prints, per phase, when workgroups reach it (percentiles over workgroups, us since the first start) and the
+per-CU residency."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+NAMES = ["start", "ca flag", "ca in LDS", "x scanned", "planes stored", "published", "neighbours", "staged", "conv", "stores issued",
+         "stores done"]
+
+
+def main():
+    plan, desc, batch = bench.make_plan("cfg2", torch.device("cuda", 0), seed=1, dtype_name="f32")
+    nblk = 4096
+    buf = torch.zeros(nblk * 16, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        plan.forward()
+    torch.cuda.synchronize()
+    os.environ["MGACBAM_TRACE_PTR"] = str(buf.data_ptr())
+    plan.forward()
+    torch.cuda.synchronize()
+    os.environ["MGACBAM_TRACE_PTR"] = ""
+    t = buf.cpu().numpy().reshape(nblk, 16)
+    used = t[:, 0] > 0
+    ids = np.nonzero(used)[0]
+    t = t[used]
+    t0 = t[:, 0].min()
+    role = t[:, 10] == 0
+    print(f"{used.sum()} workgroups traced, {role.sum()} role workgroups; clock 100 MHz -> us")
+    us = lambda v: (v - t0) / 100.0
+    tiles = t[~role]
+    print("%-16s %8s %8s %8s %8s %8s" % ("phase", "min", "p10", "p50", "p90", "max"))
+    for s, n in enumerate(NAMES):
+        v = us(tiles[:, s])
+        print("%-16s %8.2f %8.2f %8.2f %8.2f %8.2f" % (n, v.min(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), v.max()))
+    print("per-workgroup phase durations (us): median / p90")
+    for s in range(1, len(NAMES)):
+        d = (tiles[:, s] - tiles[:, s - 1]) / 100.0
+        print("  %-14s -> %-14s %7.2f %7.2f" % (NAMES[s - 1], NAMES[s], np.median(d), np.percentile(d, 90)))
+    r = t[role]
+    if len(r):
+        print("role workgroups: start p50 %.2f, MLP done p50 %.2f, published p50 %.2f max %.2f" % (
+            np.median(us(r[:, 0])), np.median(us(r[:, 3])), np.median(us(r[:, 5])), us(r[:, 5]).max()))
+    hw = tiles[:, 15]
+    xcc = hw >> 32
+    cu = (hw & 0xFFFFFFFF)
+    cu_id = (cu >> 8) & 0xF
+    se_id = (cu >> 13) & 0x7
+    key = xcc * 1000 + se_id * 16 + cu_id
+    uniq, cnt = np.unique(key, return_counts=True)
+    print(f"{len(uniq)} distinct (xcc,se,cu); workgroups per CU: min {cnt.min()} median {np.median(cnt)} max {cnt.max()}")
+    # concurrency over time: how many tile workgroups are in [start, stores done) at each us
+    life = np.stack([us(tiles[:, 0]), us(tiles[:, 10])], 1)
+    for tt in range(0, int(life[:, 1].max()) + 1, 4):
+        n = ((life[:, 0] <= tt) & (life[:, 1] > tt)).sum()
+        nload = ((us(tiles[:, 0]) <= tt) & (us(tiles[:, 3]) > tt)).sum()
+        nchain = ((us(tiles[:, 3]) <= tt) & (us(tiles[:, 8]) > tt)).sum()
+        nstore = ((us(tiles[:, 8]) <= tt) & (us(tiles[:, 10]) > tt)).sum()
+        print(f"  t={tt:3d} us: resident {n:5d}  loading {nload:5d}  chain {nchain:5d}  storing {nstore:5d}")
+    np.save("gpurun_out/trace_gate.npy", np.concatenate([ids[:, None], t], 1))
+
+
+if __name__ == "__main__":
+    main()
