@@ -53,12 +53,12 @@ struct FwdArgs {
 
 // transient backward buffers (device pointers into the caller's scratch buffer)
 struct ScratchPtrs {
-  float* A_part;    // (B,nt,2,C) per hw-tile partials: [0] sum gy*x*sa, [1] sum gy*x (k_bwd_reduce1 -> k_bwd_reduce2)
+  float* A_part;    // (B,nt,2,C) per hw-tile partials: [0] A = sum gy*x*sa, [1] D = sum gy*(v-x) (k_bwd_reduce1 -> k_bwd_reduce2)
   float* gpre;      // (B,HW)    dL/d(conv output)
   float* gplanes;   // (B,3,HW)  dL/d(planes)
   float* gwsa_part; // (nconv, 3*k*k)
   float* gz;        // (B,C)     dL/dz
-  float* gbq;       // (B,C)     ca*A - Q  (for dL/dbeta)
+  float* gbq;       // (B,C)     D = sum_hw gy*(v - x)  (for dL/dbeta)
   float* gh_avg;    // (B,hidden)
   float* gh_mx;     // (B,hidden)
   float* pgh;       // (B,ncg,hidden) per-channel-group partials of W2^T g_z (k_bwd_reduce2 -> k_bwd_apply prologue)

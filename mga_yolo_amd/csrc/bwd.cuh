@@ -2,10 +2,10 @@
 // mga_yolo/nn/modules/masked_cbam.py:87-171, restated in SURVEY.md section 8a and oracle/maskcbam_oracle.py.
 //
 // With a = softplus(beta), u = x*ca, v = u*sa, N = H*W; four launches per step, each covering P3+P4+P5:
-//   k_bwd_reduce1  x, gy (1 read each) -> A[b,c] = sum_hw gy*x*sa, Q[b,c] = sum_hw gy*x   (per hw-tile partials)
+//   k_bwd_reduce1  x, gy (1 read each) -> A[b,c] = sum_hw gy*x*sa, D[b,c] = sum_hw gy*(v-x)   (per hw-tile partials)
 //                                         g_pre[b,hw] = a * sa(1-sa) * sum_c ca*gy*x
 //   k_bwd_convT    g_pre               -> g_planes = conv_transpose(g_pre, Wsa)                    [tiny, critical path]
-//   k_bwd_reduce2  x (1 read)          -> g_ca[b,c] = a*A + sum_hw x * ([c == cidx]*gp0 + gp1/C) ; g_z ; (ca*A - Q) ;
+//   k_bwd_reduce2  x (1 read)          -> g_ca[b,c] = a*A + sum_hw x * ([c == cidx]*gp0 + gp1/C) ; g_z ; D ;
 //                                         per-channel-group partials of W2^T g_z
 //                                         + role workgroups (k_bwd_wsa body): dWsa tile partials
 //   k_bwd_apply    gy (+ x when dL/dmask is wanted) -> prologue: g_h from the partials, g_avg, g_mx = W1^T g_h ;
@@ -58,7 +58,7 @@ __device__ __forceinline__ void bwd_reduce1_body(const BwdArgs& A, const int bid
   const T* xp = static_cast<const T*>(A.x) + base;
   const T* gp = static_cast<const T*>(A.gy) + base;
   const float a = softplusf_(*A.p.beta);
-  // LDS: [C ca][2*C tile partials (A then Q)][256*VEC combine]
+  // LDS: [C ca][2*C tile partials (A then D)][256*VEC combine]
   float* s_ca = smem;
   float* s_aq = smem + g.C;
   float* sm = s_aq + 2 * g.C;
@@ -84,7 +84,7 @@ __device__ __forceinline__ void bwd_reduce1_body(const BwdArgs& A, const int bid
       const float p = xv[e] * gv[e] * live;
       accp[e] += cac * p;
       pa += p * sav[e];
-      pq += p;
+      pq += p * (cac * sav[e] - 1.f);                           // gy*(v - x), summed directly: ca*A - Q would cancel two large sums
     }
     pa = wave_group_sum(pa, TX);
     pq = wave_group_sum(pq, TX);
@@ -93,7 +93,7 @@ __device__ __forceinline__ void bwd_reduce1_body(const BwdArgs& A, const int bid
 #pragma unroll
   for (int e = 0; e < VEC; ++e) sm[tid * VEC + e] = accp[e];
   __syncthreads();
-  // this tile's partials of A[b,c] and Q[b,c], written as two contiguous runs of C floats (layout (B, nt, 2, C))
+  // this tile's partials of A[b,c] and D[b,c], written as two contiguous runs of C floats (layout (B, nt, 2, C))
   float* part = A.s.A_part + (static_cast<size_t>(b) * ntile + tile) * 2 * g.C;
   for (int c = tid; c < 2 * g.C; c += kBlock) part[c] = s_aq[c];
   if (ty == 0 && active) {
@@ -359,7 +359,7 @@ __device__ __forceinline__ void bwd_reduce2_body(const BwdArgs& A, const int bid
         const float gca = a * As + sums[j];
         gzv[j] = gca * ca * (1.f - ca);
         A.s.gz[o] = gzv[j];
-        A.s.gbq[o] = ca * As - Qs;                             // sum_hw gy*(v - x) for this (b,c)
+        A.s.gbq[o] = Qs;                                       // sum_hw gy*(v - x) for this (b,c)
       }
     }
   }
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_reduce2(const Group<BwdArgs> G) 
 //                     application) -> gh_avg, gh_mx ; dW1[j,:], db1[j], dW2[:,j]          (shared MLP used twice)
 //   [h, h+nb2)        db2[c] = 2 sum_b g_z[b,c]
 //   [.., +nb_wsa)     dWsa[p,i,j] = sum over conv tiles of the partials (one wave per output)
-//   last              dbeta = sigmoid(beta) * sum_{b,c} (ca*A - Q)
+//   last              dbeta = sigmoid(beta) * sum_{b,c} D
 //   LDS (dynamic): 3*B floats
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void bwd_params_body(const BwdArgs& A, const int local, float* sm, float* red) {

@@ -38,17 +38,17 @@ for it in range(n):
         torch.autograd.backward(list(ys), [r[2].cuda().to(r[3]) for r in ref])
         for l, ((xd, md, ps, _), (y_o, g_o, gy, dt, desc)) in enumerate(zip(lv, ref)):
             tol = {torch.float32: 1e-4, torch.float16: 4e-3, torch.bfloat16: 3e-2}[dt]
-            floor = 1e-6 * float(gy.norm() * xd.detach().float().norm().cpu())
+            floor = 1e-7 * float(gy.norm() * xd.detach().float().norm().cpu())   # absolute: fp32 rounding of a cancelling sum's terms
             checks = dict(y=(ys[l].float(), y_o), gx=(xd.grad.float(), g_o["gx"]), gw1=(ps[0].grad, g_o["gw1"]), gwsa=(ps[4].grad, g_o["gwsa"]),
                           gbeta=(ps[5].grad, g_o["gbeta"]), gw2=(ps[2].grad, g_o["gw2"]))
             if md is not None and md.requires_grad:
                 checks["gmask"] = (md.grad, g_o["gmask"])
             for name, (got, want) in checks.items():
                 dv = float((got.detach().double().cpu() - want.double()).abs().max())
-                sc = float(want.double().abs().max()) + (floor if name not in ("y", "gx") else 0.0)
-                if not dv <= tol * max(sc, 1e-30):
+                bar = tol * float(want.double().abs().max()) + (floor if name not in ("y", "gx") else 0.0)
+                if not dv <= max(bar, 1e-30):
                     bad += 1
-                    print(f"FAIL call {it} level {l} {desc} {dt}: {name} {dv / max(sc, 1e-30):.2e}", flush=True)
+                    print(f"FAIL call {it} level {l} {desc} {dt}: {name} |diff| {dv:.2e} > {bar:.2e}", flush=True)
     except Exception as ex:   # noqa: BLE001
         bad += 1
         print(f"ERROR call {it}: {[r[4] for r in ref]}: {type(ex).__name__}: {ex}", flush=True)
