@@ -104,7 +104,8 @@ def time_kernels(plan, reps):
     from mga_yolo_amd import _lib
     Bs, Fs = _lib.BWD_STAGES, _lib.FWD_STAGES
     fwd = [("fwd.pool", plan.forward, Fs["pool"])]
-    if plan.fuse_forward:
+    plan.forward()
+    if plan.gate_active():
         fwd += [("fwd.gate", plan.forward, Fs["chan"] | Fs["apply"])]     # one x-resident launch (plan adds FWD_FUSE)
     else:
         fwd += [("fwd.chan", plan.forward, Fs["chan"]), ("fwd.apply", plan.forward, Fs["apply"])]

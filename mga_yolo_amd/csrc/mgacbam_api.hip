@@ -152,7 +152,7 @@ static Tune choose_tune(int B, int C, int H, int W, int k, int dtype = MGACBAM_F
   t.apply_rows = rows + k - 1;
   t.nt_stores = env_int("MGACBAM_NT", 1) ? 1 : 0;
   // k_gate (x-resident chan+apply): every thread keeps kGateR channels, so TY = ceil(C / kGateR) slices (power of two) and the
-  // rest of the 256 threads go along H*W.  Eligible when a tile is >= kSyncPx pixels (ctx.sync has one flag per kSyncPx),
+  // rest of the 256 threads go along H*W.  Eligible when a tile is >= kSyncPx pixels (ctx.sync has one flag per kSyncPx) and >= one image row,
   // the tiles a k x k window reaches are few (their workgroups must be co-resident: 8 ids apart per tile, common.cuh) and
   // the staged rows fit in LDS; otherwise the three-launch forward runs.
   t.gate_tx = 0; t.gate_rows = 0;
@@ -164,7 +164,9 @@ static Tune choose_tune(int B, int C, int H, int W, int k, int dtype = MGACBAM_F
     grows += k - 1;
     const int span = ((k / 2) * W + TP - 1) / TP + 1;           // tiles reached on either side
     const size_t lds = (3 * static_cast<size_t>(grows) * (W + k - 1) + TP + 3 * k * k + 3 * C + 64) * sizeof(float);
-    if (TP >= kSyncPx && 8 * span <= 256 && lds <= 48 * 1024) { t.gate_tx = gtx; t.gate_rows = grows; }
+    // TP >= W: a tile narrower than an image row stages k+1 full rows for a fraction of a row of outputs (measured at
+    // 1280-px inputs, C = 256/512: k_gate 220 us against 207 us for k_chan + k_apply; at >= 1.6 rows per tile it wins 18-20 %)
+    if (TP >= kSyncPx && TP >= W && 8 * span <= 256 && lds <= 48 * 1024) { t.gate_tx = gtx; t.gate_rows = grows; }
   }
   return t;
 }

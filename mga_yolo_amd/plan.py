@@ -78,6 +78,14 @@ class PyramidPlan:
             stages |= _lib.FWD_FUSE     # ctx is zero-filled at allocation, as the flag's contract asks
         _lib.check(self.lib.mgacbam_forward_stages(self._fwd, self.n, stages, self._stream()), "mgacbam_forward_stages")
 
+    def gate_active(self) -> bool:
+        """True when the last fused forward really ran k_gate (the library falls back to k_chan + k_apply for groups with a
+        level whose shape is not eligible): k_gate bumps the hand-off flags at the end of ctx, the fallback never touches them."""
+        if not self.fuse_forward:
+            return False
+        torch.cuda.synchronize(self.device)
+        return all(int(self.ctx_view(l)["sync"].max()) > 0 for l in range(self.n))
+
     def backward(self, stages: int = _lib.BWD_ALL):
         _lib.check(self.lib.mgacbam_backward_stages(self._bwd, self.n, stages, self._stream()), "mgacbam_backward_stages")
 
