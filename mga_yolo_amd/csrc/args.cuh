@@ -73,6 +73,7 @@ struct BwdArgs {
   int nwsa;     // k_bwd_wsa tiles of this level: one dWsa partial each
   int npg;      // parameter-gradient workgroups of this level (k_bwd_params roles)
   int ncg;      // channel groups per sample of k_bwd_reduce2
+  long long* trace;   // MGACBAM_TRACE builds only (tools/trace_gate.py), else nullptr
 };
 
 static inline size_t align16(size_t v) { return (v + 15) & ~size_t(15); }

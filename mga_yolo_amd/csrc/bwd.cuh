@@ -542,6 +542,9 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
   const bool has_mask = A.mask != nullptr;
   const size_t po = static_cast<size_t>(b) * g.HW + static_cast<size_t>(ii) * VEC;
 
+  const int gid = blockIdx.x;
+  TRACE_HWID(A.trace, gid);
+  TRACE_MARK(A.trace, gid, 0);
   float sav[VEC], g0[VEC], g1[VEC], sv[VEC], wA[VEC];
   int ci[VEC];
   load_vec<float, VEC>(A.c.sa + po, sav);
@@ -616,6 +619,7 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
       __syncthreads();
     }
   }
+  TRACE_MARK(A.trace, gid, 1);                                 // hidden gradient in LDS
   if (early) {
     // per-channel operands were requested before the partial-sum barriers (one global-load latency instead of two)
     if (tid < g.C) {
@@ -653,6 +657,7 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
   if (tid == 0) red[7] = kpart;
   __syncthreads();
   const float kb = red[7];
+  TRACE_MARK(A.trace, gid, 2);                                 // per-channel terms in LDS
 
   auto emit = [&](const float (&gv)[VEC], const float (&xv)[VEC], int c) {
     float ov[VEC];
@@ -681,6 +686,7 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
     if (GMASK) { if (need_x) load_vec<T, VEC>(xp + static_cast<size_t>(c) * g.HW, xv); }
     emit(gv, xv, c);
   }
+  TRACE_MARK(A.trace, gid, 3);                                 // streaming loop done (stores issued)
   if (GMASK) {
     if (need_x) {
 #pragma unroll
@@ -713,10 +719,18 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
       store_vec<float, VEC>(A.gmask + static_cast<size_t>(b) * g.HW + static_cast<size_t>(i) * VEC, gm);
     }
   }
+#ifdef MGACBAM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  TRACE_MARK(A.trace, gid, 10);                                // stores complete
+#endif
 }
 
 // ROLES: the level's grid is [npg parameter-gradient workgroups][streaming workgroups]; the tiny, latency-bound
 // parameter kernel hides behind the largest kernel of the step instead of standing alone on the critical path.
+// (amdgpu_waves_per_eu(5) -- 94 instead of 104 VGPRs, 5 instead of 4 workgroups per CU -- was measured: config 2 fp32 57.9 -> 55.8 us,
+//  bf16 37.3 -> 38.5, config 4 200 -> 225 us; not adopted.  tools/trace_gate.py bwd shows the launch as two rounds of
+//  ~5 us prologue + ~19 us streaming per workgroup with HBM saturated during the streaming.)
 template <typename T, int VEC, bool GMASK, bool ROLES>
 __global__ __launch_bounds__(kBlock) void k_bwd_apply(const Group<BwdArgs> G) {
   extern __shared__ __align__(16) float smem[];
@@ -726,7 +740,18 @@ __global__ __launch_bounds__(kBlock) void k_bwd_apply(const Group<BwdArgs> G) {
   const BwdArgs& A = G.lv[l];
   if (ROLES) {
     const int npad = (A.npg + 7) & ~7;
-    if (local < npad) { if (local < A.npg) bwd_params_body(A, local, smem, red); return; }
+    if (local < npad) {
+      if (local < A.npg) {
+        TRACE_MARK(A.trace, blockIdx.x, 0);
+        bwd_params_body(A, local, smem, red);
+#ifdef MGACBAM_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        TRACE_MARK(A.trace, blockIdx.x, 9);
+#endif
+      }
+      return;
+    }
     local -= npad;
   }
   bwd_apply_body<T, VEC, GMASK>(A, local, smem, red);

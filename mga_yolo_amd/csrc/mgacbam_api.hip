@@ -472,6 +472,7 @@ static int backward_args(const mgacbam_bwd_level_t& L, BwdArgs& A, Sig& sig) {
   A.nwsa = A.g.B * wsa_tiles(A.t, A.g.H, A.g.W);
   A.npg = params_blocks(A.g);
   A.ncg = 0;
+  { const char* tp = getenv("MGACBAM_TRACE_PTR"); A.trace = (tp && *tp) ? reinterpret_cast<long long*>(strtoull(tp, nullptr, 0)) : nullptr; }
   const int proj = (L.flags & MGACBAM_BWD_HAVE_PROJ) && L.gmask != nullptr;
   A.g.proj_h = (proj && L.p.hidden <= MGACBAM_PROJ_MAX_HIDDEN) ? L.p.hidden : 0;
   sig = Sig{L.dtype, VEC, L.mask != nullptr, L.p.k, L.gmask != nullptr, proj};

@@ -12,19 +12,30 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-NAMES = ["start", "ca flag", "ca in LDS", "x scanned", "planes stored", "published", "neighbours", "staged", "conv", "stores issued",
-         "stores done"]
+NAMES_FWD = ["start", "ca flag", "ca in LDS", "x scanned", "planes stored", "published", "neighbours", "staged", "conv", "stores issued",
+             "stores done"]
+NAMES_BWD = ["start", "g_h", "terms", "loop done", "-", "-", "-", "-", "-", "-", "stores done"]   # k_bwd_apply
 
 
 def main():
     plan, desc, batch = bench.make_plan("cfg2", torch.device("cuda", 0), seed=1, dtype_name="f32")
     nblk = 4096
     buf = torch.zeros(nblk * 16, dtype=torch.int64, device="cuda")
+    which = sys.argv[1] if len(sys.argv) > 1 else "fwd"       # fwd: k_gate, bwd: k_bwd_apply
+    NAMES = NAMES_FWD if which == "fwd" else NAMES_BWD
+    S = __import__("mga_yolo_amd")._lib.BWD_STAGES
     for _ in range(3):
-        plan.forward()
+        plan.forward(); plan.backward()
     torch.cuda.synchronize()
-    os.environ["MGACBAM_TRACE_PTR"] = str(buf.data_ptr())
-    plan.forward()
+    if which == "fwd":
+        os.environ["MGACBAM_TRACE_PTR"] = str(buf.data_ptr())
+        plan.forward()
+    else:
+        plan.forward()
+        plan.backward(S["reduce1"]); plan.backward(S["convT"]); plan.backward(S["reduce2"] | S["wsa"] | 64)
+        torch.cuda.synchronize()
+        os.environ["MGACBAM_TRACE_PTR"] = str(buf.data_ptr())
+        plan.backward(S["params"] | S["apply"] | 64)
     torch.cuda.synchronize()
     os.environ["MGACBAM_TRACE_PTR"] = ""
     t = buf.cpu().numpy().reshape(nblk, 16)
@@ -33,21 +44,26 @@ def main():
     t = t[used]
     t0 = t[:, 0].min()
     role = t[:, 10] == 0
+    nblk_seen = used.sum()
     print(f"{used.sum()} workgroups traced, {role.sum()} role workgroups; clock 100 MHz -> us")
     us = lambda v: (v - t0) / 100.0
     tiles = t[~role]
     print("%-16s %8s %8s %8s %8s %8s" % ("phase", "min", "p10", "p50", "p90", "max"))
     for s, n in enumerate(NAMES):
+        if n == "-":
+            continue
         v = us(tiles[:, s])
         print("%-16s %8.2f %8.2f %8.2f %8.2f %8.2f" % (n, v.min(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), v.max()))
     print("per-workgroup phase durations (us): median / p90")
-    for s in range(1, len(NAMES)):
-        d = (tiles[:, s] - tiles[:, s - 1]) / 100.0
-        print("  %-14s -> %-14s %7.2f %7.2f" % (NAMES[s - 1], NAMES[s], np.median(d), np.percentile(d, 90)))
+    live = [s for s, n in enumerate(NAMES) if n != "-"]
+    for s0, s1 in zip(live[:-1], live[1:]):
+        d = (tiles[:, s1] - tiles[:, s0]) / 100.0
+        print("  %-14s -> %-14s %7.2f %7.2f" % (NAMES[s0], NAMES[s1], np.median(d), np.percentile(d, 90)))
     r = t[role]
     if len(r):
-        print("role workgroups: start p50 %.2f, MLP done p50 %.2f, published p50 %.2f max %.2f" % (
-            np.median(us(r[:, 0])), np.median(us(r[:, 3])), np.median(us(r[:, 5])), us(r[:, 5]).max()))
+        last = 5 if which == "fwd" else 9
+        print("role workgroups: start p50 %.2f, done p50 %.2f p90 %.2f max %.2f" % (
+            np.median(us(r[:, 0])), np.median(us(r[:, last])), np.percentile(us(r[:, last]), 90), us(r[:, last]).max()))
     hw = tiles[:, 15]
     xcc = hw >> 32
     cu = (hw & 0xFFFFFFFF)
@@ -60,9 +76,10 @@ def main():
     life = np.stack([us(tiles[:, 0]), us(tiles[:, 10])], 1)
     for tt in range(0, int(life[:, 1].max()) + 1, 4):
         n = ((life[:, 0] <= tt) & (life[:, 1] > tt)).sum()
-        nload = ((us(tiles[:, 0]) <= tt) & (us(tiles[:, 3]) > tt)).sum()
-        nchain = ((us(tiles[:, 3]) <= tt) & (us(tiles[:, 8]) > tt)).sum()
-        nstore = ((us(tiles[:, 8]) <= tt) & (us(tiles[:, 10]) > tt)).sum()
+        a_, b_ = (3, 8) if which == "fwd" else (2, 3)          # bwd: "loading" = prologue, "chain" = streaming loop
+        nload = ((us(tiles[:, 0]) <= tt) & (us(tiles[:, a_]) > tt)).sum()
+        nchain = ((us(tiles[:, a_]) <= tt) & (us(tiles[:, b_]) > tt)).sum()
+        nstore = ((us(tiles[:, b_]) <= tt) & (us(tiles[:, 10]) > tt)).sum()
         print(f"  t={tt:3d} us: resident {n:5d}  loading {nload:5d}  chain {nchain:5d}  storing {nstore:5d}")
     np.save("gpurun_out/trace_gate.npy", np.concatenate([ids[:, None], t], 1))
 
