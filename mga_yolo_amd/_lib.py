@@ -68,6 +68,18 @@ class CtxLayout(C.Structure):                    # mgacbam_ctx_layout_t
 
 
 # every symbol include/mgacbam.h declares: (restype, argtypes)
+class SegLevel(C.Structure):                     # mgaseg_level_t
+    _fields_ = [("logits", C.c_void_p), ("target", C.c_void_p), ("glogits", C.c_void_p),
+                ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ht", C.c_int32), ("Wt", C.c_int32),
+                ("dtype", C.c_int32), ("scale_weight", C.c_float)]
+
+
+class SegCfg(C.Structure):                       # mgaseg_cfg_t
+    _fields_ = [("bce_weight", C.c_float), ("dice_weight", C.c_float), ("smooth", C.c_float), ("loss_lambda", C.c_float)]
+
+
+SEG_MAX_LEVELS = 4
+
 SYMBOLS = {
     "mgacbam_abi_version": (C.c_int, []),
     "mgacbam_last_error": (C.c_char_p, []),
@@ -84,6 +96,9 @@ SYMBOLS = {
     "mgacbam_eca_scratch_bytes": (C.c_size_t, [C.c_int] * 4),
     "mgacbam_eca_forward": (C.c_int, [C.POINTER(EcaFwdLevel), C.c_int, C.c_void_p]),
     "mgacbam_eca_backward": (C.c_int, [C.POINTER(EcaBwdLevel), C.c_int, C.c_void_p]),
+    "mgaseg_ws_bytes": (C.c_size_t, [C.POINTER(SegLevel), C.c_int]),
+    "mgaseg_forward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgaseg_backward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -15,6 +15,7 @@
 #include "bwd.cuh"
 #include "common.cuh"
 #include "eca.cuh"
+#include "segloss.cuh"
 #include "fwd.cuh"
 
 using namespace mgacbam;
@@ -746,6 +747,83 @@ extern "C" int mgacbam_resize_nearest(const float* src, float* dst, int n_planes
   hipLaunchKernelGGL(k_resize_nearest, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                      src, dst, n_planes, in_h, in_w, out_h, out_w);
   if (int e = launch_status("k_resize_nearest")) return e;
+  g_err[0] = 0;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// segmentation loss
+// ------------------------------------------------------------------------------------------------
+static int seg_check(const mgaseg_level_t* levels, int n, const mgaseg_cfg_t* cfg, bool bwd) {
+  if (!levels || !cfg) return fail(MGACBAM_E_NULL, "segloss: NULL argument");
+  if (n < 1 || n > MGASEG_MAX_LEVELS) return fail(MGACBAM_E_LEVELS, "segloss: n_levels=%d", n);
+  for (int l = 0; l < n; ++l) {
+    const mgaseg_level_t& L = levels[l];
+    if (!L.logits || !L.target || (bwd && !L.glogits)) return fail(MGACBAM_E_NULL, "segloss: level %d has a NULL pointer", l);
+    if (L.B < 1 || L.H < 1 || L.W < 1 || L.Ht < 1 || L.Wt < 1 || static_cast<long long>(L.H) * L.W > (1ll << 30))
+      return fail(MGACBAM_E_SHAPE, "segloss: level %d bad shape B=%d H=%d W=%d Ht=%d Wt=%d", l, L.B, L.H, L.W, L.Ht, L.Wt);
+    if (L.dtype != levels[0].dtype || L.dtype < MGACBAM_F32 || L.dtype > MGACBAM_BF16) return fail(MGACBAM_E_DTYPE, "segloss: dtype %d", L.dtype);
+  }
+  return 0;
+}
+static size_t seg_ws_level(int B) { return align16(static_cast<size_t>(B) * (kSegParts + 1) * 4 * sizeof(float)); }
+extern "C" size_t mgaseg_ws_bytes(const mgaseg_level_t* levels, int n) {
+  if (!levels || n < 1 || n > MGASEG_MAX_LEVELS) { fail(MGACBAM_E_LEVELS, "segloss: n_levels=%d", n); return 0; }
+  size_t tot = 0;
+  for (int l = 0; l < n; ++l) tot += seg_ws_level(levels[l].B);
+  return tot;
+}
+static int seg_args(const mgaseg_level_t* levels, int n, const mgaseg_cfg_t* cfg, void* ws, SegArgs& A) {
+  A.n = n;
+  char* w = static_cast<char*>(ws);
+  int tot = 0;
+  for (int l = 0; l < n; ++l) {
+    const mgaseg_level_t& L = levels[l];
+    SegLevel& S = A.lv[l];
+    S.logits = L.logits; S.target = L.target; S.glogits = L.glogits;
+    S.part = reinterpret_cast<float*>(w);
+    S.sums = S.part + static_cast<size_t>(L.B) * kSegParts * 4;
+    w += seg_ws_level(L.B);
+    S.B = L.B; S.H = L.H; S.W = L.W; S.Ht = L.Ht; S.Wt = L.Wt; S.w_scale = L.scale_weight;
+    A.start[l] = tot;
+    tot += L.B * kSegParts;
+  }
+  A.start[n] = tot;
+  A.w_bce = cfg->bce_weight; A.w_dice = cfg->dice_weight; A.smooth = cfg->smooth; A.lambda = cfg->loss_lambda;
+  A.out = nullptr; A.gout = nullptr;
+  return tot;
+}
+extern "C" int mgaseg_forward(const mgaseg_level_t* levels, int n, const mgaseg_cfg_t* cfg, void* ws, float* out, void* stream) {
+  if (int e = seg_check(levels, n, cfg, false)) return e;
+  if (!ws || !out) return fail(MGACBAM_E_NULL, "segloss: ws / out is NULL");
+  SegArgs A;
+  const int grid = seg_args(levels, n, cfg, ws, A);
+  A.out = out;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (levels[0].dtype) {
+    case MGACBAM_F32: LAUNCH(k_seg_partial<float>, grid, 0, st, A); break;
+    case MGACBAM_F16: LAUNCH(k_seg_partial<__half>, grid, 0, st, A); break;
+    default: LAUNCH(k_seg_partial<bf16_t>, grid, 0, st, A); break;
+  }
+  if (int e = launch_status("k_seg_partial")) return e;
+  LAUNCH(k_seg_final, 1, 0, st, A);
+  if (int e = launch_status("k_seg_final")) return e;
+  g_err[0] = 0;
+  return 0;
+}
+extern "C" int mgaseg_backward(const mgaseg_level_t* levels, int n, const mgaseg_cfg_t* cfg, const void* ws, const float* gout, void* stream) {
+  if (int e = seg_check(levels, n, cfg, true)) return e;
+  if (!ws || !gout) return fail(MGACBAM_E_NULL, "segloss: ws / gout is NULL");
+  SegArgs A;
+  const int grid = seg_args(levels, n, cfg, const_cast<void*>(ws), A);
+  A.gout = gout;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (levels[0].dtype) {
+    case MGACBAM_F32: LAUNCH(k_seg_bwd<float>, grid, 0, st, A); break;
+    case MGACBAM_F16: LAUNCH(k_seg_bwd<__half>, grid, 0, st, A); break;
+    default: LAUNCH(k_seg_bwd<bf16_t>, grid, 0, st, A); break;
+  }
+  if (int e = launch_status("k_seg_bwd")) return e;
   g_err[0] = 0;
   return 0;
 }

@@ -1,0 +1,132 @@
+// Multi-scale segmentation loss on the mask logits: BCE-with-logits (mean) + soft Dice per level, summed with the
+// scale weights.                                                         mga_yolo/nn/losses/segmentation.py:38-42, 87-151
+//   forward : k_seg_partial  (sample b, part) -> partial sums {bce, p*t, p, t}   ;  k_seg_final: per level bce = sum/(B*HW),
+//             dice_b = 1 - (2 I_b + s)/(P_b + T_b + s), combined = w_l (w_bce bce + w_dice mean_b dice_b), total = lambda * sum_l
+//   backward: k_seg_bwd      g_x = g_total * lambda * w_l * [ w_bce (p - t)/(B*HW) + w_dice/B * d dice_b/d p * p(1-p) ]
+//             d dice_b / d p_i = -(2 t_i D_b - (2 I_b + s)) / D_b^2,  D_b = P_b + T_b + s
+// The target may live at another resolution: it is gathered with F.interpolate(mode="nearest")'s index rule on the fly
+// (segmentation.py:103-110; same integer path as k_resize_nearest).  All tensors are B x 1 x H x W: the whole loss is a few MB, so
+// the kernels are launch/latency-bound; one launch covers every level, sums are two-stage with a fixed order (reproducible).
+#pragma once
+#include "common.cuh"
+
+namespace mgacbam {
+
+constexpr int kSegMaxLevels = 4;
+constexpr int kSegParts = 8;       // workgroups per sample and level
+
+struct SegLevel {
+  const void* logits;   // (B,1,H,W) T
+  const float* target;  // (B,1,Ht,Wt) fp32
+  void* glogits;        // (B,1,H,W) T, backward only
+  float* part;          // (B, kSegParts, 4) partial sums            (workspace)
+  float* sums;          // (B, 4) per-sample {bce, I, P, T}           (workspace, saved for backward)
+  int B, H, W, Ht, Wt;
+  float w_scale;
+};
+struct SegArgs {
+  int n;
+  int start[kSegMaxLevels + 1];     // workgroup ids of level l: [start[l], start[l+1])
+  SegLevel lv[kSegMaxLevels];
+  float w_bce, w_dice, smooth, lambda;
+  float* out;                       // [0] total, then per level {bce, dice, combined}
+  const float* gout;                // backward: dL/d(total), device scalar
+};
+
+__device__ __forceinline__ float seg_target(const SegLevel& L, int b, int y, int x) {
+  if (L.Ht == L.H && L.Wt == L.W) return L.target[(static_cast<size_t>(b) * L.H + y) * L.W + x];
+  const float sh = static_cast<float>(L.Ht) / static_cast<float>(L.H), sw = static_cast<float>(L.Wt) / static_cast<float>(L.W);
+  const int sy = min(static_cast<int>(floorf(static_cast<float>(y) * sh)), L.Ht - 1);
+  const int sx = min(static_cast<int>(floorf(static_cast<float>(x) * sw)), L.Wt - 1);
+  return L.target[(static_cast<size_t>(b) * L.Ht + sy) * L.Wt + sx];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_seg_partial(const SegArgs A) {
+  __shared__ float red[8];
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < kSegMaxLevels; ++i)
+    if (i < A.n && static_cast<int>(blockIdx.x) >= A.start[i]) l = i;
+  const SegLevel& L = A.lv[l];
+  const int local = blockIdx.x - A.start[l];
+  const int b = local / kSegParts, part = local - b * kSegParts;
+  const int HW = L.H * L.W;
+  const T* xp = static_cast<const T*>(L.logits) + static_cast<size_t>(b) * HW;
+  float s_bce = 0.f, s_i = 0.f, s_p = 0.f, s_t = 0.f;
+  for (int i = part * kBlock + threadIdx.x; i < HW; i += kSegParts * kBlock) {
+    const float x = to_f32<T>(xp[i]);
+    const int y = i / L.W;
+    const float t = seg_target(L, b, y, i - y * L.W);
+    const float e = expf(-fabsf(x));
+    s_bce += fmaxf(x, 0.f) - x * t + log1pf(e);              // binary_cross_entropy_with_logits, elementwise
+    const float p = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);   // sigmoid
+    s_i += p * t; s_p += p; s_t += t;
+  }
+  float v[4] = {s_bce, s_i, s_p, s_t};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float r = block_sum(v[q], threadIdx.x, red);
+    if (threadIdx.x == 0) L.part[(static_cast<size_t>(b) * kSegParts + part) * 4 + q] = r;
+  }
+}
+
+// one workgroup: per-sample sums (fixed order), the level terms and the total
+__global__ __launch_bounds__(kBlock) void k_seg_final(const SegArgs A) {
+  __shared__ float red[8];
+  float total = 0.f;
+  for (int l = 0; l < A.n; ++l) {
+    const SegLevel& L = A.lv[l];
+    float bce = 0.f, dice = 0.f;
+    for (int b = threadIdx.x; b < L.B; b += kBlock) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int p = 0; p < kSegParts; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] += L.part[(static_cast<size_t>(b) * kSegParts + p) * 4 + q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) L.sums[b * 4 + q] = s[q];
+      bce += s[0];
+      dice += 1.f - (2.f * s[1] + A.smooth) / (s[2] + s[3] + A.smooth);        // segmentation.py:38-42
+    }
+    bce = block_sum(bce, threadIdx.x, red);
+    dice = block_sum(dice, threadIdx.x, red);
+    if (threadIdx.x == 0) {
+      bce /= static_cast<float>(L.B) * static_cast<float>(L.H * L.W);          // BCEWithLogitsLoss(reduction="mean")
+      dice /= static_cast<float>(L.B);
+      const float comb = L.w_scale * (A.w_bce * bce + A.w_dice * dice);        // segmentation.py:134-136
+      A.out[1 + 3 * l] = bce; A.out[2 + 3 * l] = dice; A.out[3 + 3 * l] = comb;
+      total += comb;
+    }
+  }
+  if (threadIdx.x == 0) A.out[0] = total * A.lambda;                           // segmentation.py:149
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_seg_bwd(const SegArgs A) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < kSegMaxLevels; ++i)
+    if (i < A.n && static_cast<int>(blockIdx.x) >= A.start[i]) l = i;
+  const SegLevel& L = A.lv[l];
+  const int local = blockIdx.x - A.start[l];
+  const int b = local / kSegParts, part = local - b * kSegParts;
+  const int HW = L.H * L.W;
+  const T* xp = static_cast<const T*>(L.logits) + static_cast<size_t>(b) * HW;
+  T* gp = static_cast<T*>(L.glogits) + static_cast<size_t>(b) * HW;
+  const float g = *A.gout * A.lambda * L.w_scale;
+  const float I = L.sums[b * 4 + 1], D = L.sums[b * 4 + 2] + L.sums[b * 4 + 3] + A.smooth;
+  const float kb = g * A.w_bce / (static_cast<float>(L.B) * static_cast<float>(HW));
+  const float kd = g * A.w_dice / static_cast<float>(L.B);
+  const float num = 2.f * I + A.smooth, invD2 = 1.f / (D * D);
+  for (int i = part * kBlock + threadIdx.x; i < HW; i += kSegParts * kBlock) {
+    const float x = to_f32<T>(xp[i]);
+    const int y = i / L.W;
+    const float t = seg_target(L, b, y, i - y * L.W);
+    const float e = expf(-fabsf(x));
+    const float p = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    const float ddice = -(2.f * t * D - num) * invD2;
+    gp[i] = from_f32<T>(kb * (p - t) + kd * ddice * p * (1.f - p));
+  }
+}
+
+}  // namespace mgacbam

@@ -13,10 +13,14 @@ import sys
 from typing import List
 
 from .module import MaskCBAM, MaskECA
+from .segloss import SegLossConfig, SegmentationLoss
 
 _TARGETS = ("ultralytics.nn.tasks", "ultralytics.nn", "ultralytics.nn.modules",
             "mga_yolo.nn.modules.masked_cbam", "mga_yolo.nn.modules.masked_eca", "mga_yolo.nn.modules", "mga_yolo.nn")
 _CLASSES = {"MaskCBAM": MaskCBAM, "MaskECA": MaskECA}      # parse_model treats both through the same branch (U/nn/tasks.py:1733)
+# MGAModel.init_criterion imports these two names from this module at call time (mga_yolo/model/model.py:103-117)
+_LOSS_TARGET = "mga_yolo.nn.losses.segmentation"
+_LOSS_CLASSES = {"SegmentationLoss": SegmentationLoss, "SegLossConfig": SegLossConfig}
 
 
 def install(strict: bool = False) -> List[str]:
@@ -37,6 +41,16 @@ def install(strict: bool = False) -> List[str]:
                 hit = True
         if hit:
             patched.append(name)
+    mod = sys.modules.get(_LOSS_TARGET)
+    if mod is None:
+        try:
+            mod = importlib.import_module(_LOSS_TARGET)
+        except Exception:
+            mod = None
+    if mod is not None:
+        for cls_name, cls in _LOSS_CLASSES.items():
+            setattr(mod, cls_name, cls)
+        patched.append(_LOSS_TARGET)
     if strict and "ultralytics.nn.tasks" not in patched:
         raise RuntimeError("ultralytics.nn.tasks is not importable: nothing to install into")
     return patched

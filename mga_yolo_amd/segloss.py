@@ -1,0 +1,192 @@
+"""Multi-scale segmentation loss of MGA-YOLO behind the reference's interface.
+
+Mirrors mga_yolo/nn/losses/segmentation.py: `SegLossConfig` :9-21 and `SegmentationLoss` :23-151 (same constructor, same
+`forward(preds: {"p3"|"p4"|"p5": logits}, targets: [mask, ...]) -> (total, logs)`, same log keys, same FloatingPointError on a
+non-finite value).  Device tensors in the default mode (BCE-with-logits + soft Dice) go through the HIP entry points
+`mgaseg_forward` / `mgaseg_backward` (include/mgacbam.h): two launches forward and one backward for all levels, the nearest target
+resize done inside the kernels with F.interpolate's index rule.  Host tensors, and the Unified-Focal mode (off in every shipped
+config), use the same torch ops as the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+SCALE_KEYS = ("p3", "p4", "p5")
+_DTYPE_CODES = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+
+
+@dataclass
+class SegLossConfig:
+    bce_weight: float = 1.0
+    dice_weight: float = 1.0
+    scale_weights: Sequence[float] = (1.0, 1.0, 1.0)
+    smooth: float = 1.0
+    loss_lambda: float = 1.0
+    enabled: bool = True
+    use_unified_focal: bool = False
+    ufl_lambda: float = 0.5
+    ufl_delta: float = 0.6
+    ufl_gamma: float = 0.5
+
+
+class _SegFn(torch.autograd.Function):
+    """flat = n x (logits, target); returns out = [total, (bce, dice, combined) per level] on the device."""
+
+    @staticmethod
+    def forward(ctx, cfg: Tuple[float, float, float, float], weights: Tuple[float, ...], *flat):
+        n = len(flat) // 2
+        lib = _lib.load()
+        levels = (_lib.SegLevel * n)()
+        keep = []
+        dev = flat[0].device
+        for l in range(n):
+            x, t = flat[2 * l], flat[2 * l + 1]
+            xc = x.contiguous()
+            tc = t.detach().to(torch.float32).contiguous()
+            B, _, H, W = xc.shape
+            L = levels[l]
+            L.logits, L.target, L.glogits = xc.data_ptr(), tc.data_ptr(), None
+            L.B, L.H, L.W, L.Ht, L.Wt = B, H, W, tc.shape[-2], tc.shape[-1]
+            L.dtype, L.scale_weight = _DTYPE_CODES[xc.dtype], weights[l]
+            keep += [xc, tc]
+        c = _lib.SegCfg(*cfg)
+        ws = torch.empty(lib.mgaseg_ws_bytes(levels, n), dtype=torch.uint8, device=dev)
+        out = torch.empty(1 + 3 * n, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.mgaseg_forward(levels, n, C.byref(c), ws.data_ptr(), out.data_ptr(),
+                                          torch.cuda.current_stream(dev).cuda_stream), "mgaseg_forward")
+        ctx.save_for_backward(ws, *keep)
+        ctx.cfg, ctx.weights = cfg, weights
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        ws, *keep = ctx.saved_tensors
+        n = len(keep) // 2
+        lib = _lib.load()
+        levels = (_lib.SegLevel * n)()
+        dev = ws.device
+        grads = []
+        for l in range(n):
+            xc, tc = keep[2 * l], keep[2 * l + 1]
+            gx = torch.empty_like(xc)
+            B, _, H, W = xc.shape
+            L = levels[l]
+            L.logits, L.target, L.glogits = xc.data_ptr(), tc.data_ptr(), gx.data_ptr()
+            L.B, L.H, L.W, L.Ht, L.Wt = B, H, W, tc.shape[-2], tc.shape[-1]
+            L.dtype, L.scale_weight = _DTYPE_CODES[xc.dtype], ctx.weights[l]
+            grads += [gx, None]
+        g0 = gout[0:1].to(torch.float32).contiguous()       # only `total` is differentiable; the log entries are detached copies
+        c = _lib.SegCfg(*ctx.cfg)
+        with torch.cuda.device(dev):
+            _lib.check(lib.mgaseg_backward(levels, n, C.byref(c), ws.data_ptr(), g0.data_ptr(),
+                                           torch.cuda.current_stream(dev).cuda_stream), "mgaseg_backward")
+        return (None, None, *grads)
+
+
+def _dice_probs(probs, tgt, smooth):
+    inter = (probs * tgt).sum(dim=(1, 2, 3))
+    denom = probs.sum(dim=(1, 2, 3)) + tgt.sum(dim=(1, 2, 3)) + smooth
+    return 1.0 - (2.0 * inter + smooth) / denom
+
+
+def _lmf(x, t, delta, gamma, eps=1e-6):
+    probs = torch.sigmoid(x)
+    pt = torch.where(t > 0.5, probs, 1.0 - probs).clamp(eps, 1.0 - eps)
+    ce = F.binary_cross_entropy_with_logits(x, t, reduction="none").float()
+    w = torch.where(t > 0.5, delta, 1.0 - delta).float()
+    return ((1.0 - pt).clamp_min(eps).pow(1.0 - gamma) * ce * w).mean()
+
+
+def _lmft(x, t, delta, gamma, smooth, eps=1e-6):
+    p = torch.sigmoid(x)
+    tp = (p * t).sum(dim=(1, 2, 3))
+    fn = (t * (1.0 - p)).sum(dim=(1, 2, 3))
+    fp = ((1.0 - t) * p).sum(dim=(1, 2, 3))
+    mti = (tp + smooth) / (tp + delta * fn + (1.0 - delta) * fp + smooth).clamp_min(eps)
+    return (1.0 - mti).clamp_min(eps).pow(gamma).mean()
+
+
+class SegmentationLoss(nn.Module):
+    def __init__(self, cfg: SegLossConfig) -> None:
+        super().__init__()
+        self.cfg = cfg
+
+    def forward(self, preds: Dict[str, torch.Tensor], targets: List[torch.Tensor]) -> Tuple[torch.Tensor, Dict[str, float]]:
+        cfg = self.cfg
+        first = next(iter(preds.values()))
+        if not cfg.enabled:
+            return torch.zeros((), device=first.device), {}
+        used = []
+        prob_mode = bool(os.getenv("MGA_PROB_MODE", False))
+        for i, sk in enumerate(SCALE_KEYS):
+            if sk not in preds or i >= len(targets):
+                continue
+            pred, tgt = preds[sk], targets[i]
+            if tgt.dim() == 3:
+                tgt = tgt.unsqueeze(1)
+            if tgt.shape[-2:] != pred.shape[-2:] and prob_mode:      # probabilistic masks: bilinear, as the reference
+                tgt = F.interpolate(tgt.float(), size=pred.shape[-2:], mode="bilinear", align_corners=False)
+            w = cfg.scale_weights[i] if i < len(cfg.scale_weights) else 1.0
+            used.append((sk, pred, tgt, float(w)))
+        if not used:
+            return torch.zeros((), device=first.device, dtype=torch.float32) * cfg.loss_lambda, {"seg_total": 0.0}
+        on_device = all(p.is_cuda for _, p, _, _ in used)
+        same_dtype = len({p.dtype for _, p, _, _ in used}) == 1 and used[0][1].dtype in _DTYPE_CODES
+        if on_device and same_dtype and not cfg.use_unified_focal and len(used) <= _lib.SEG_MAX_LEVELS:
+            return self._device_forward(used)
+        return self._torch_forward(used)
+
+    # ---- HIP path ---------------------------------------------------------------------------------------------------------
+    def _device_forward(self, used):
+        cfg = self.cfg
+        flat = []
+        for _, pred, tgt, _ in used:
+            if pred.dim() != 4 or pred.shape[1] != 1 or tgt.shape[0] != pred.shape[0] or tgt.shape[1] != 1:
+                raise RuntimeError(f"SegmentationLoss: logits {tuple(pred.shape)} / target {tuple(tgt.shape)} must be (B,1,H,W)")
+            flat += [pred, tgt.to(pred.device)]
+        out = _SegFn.apply((float(cfg.bce_weight), float(cfg.dice_weight), float(cfg.smooth), float(cfg.loss_lambda)),
+                           tuple(w for *_, w in used), *flat)
+        vals = out.detach().cpu().tolist()                          # ONE device->host copy for every log entry
+        logs: Dict[str, float] = {}
+        for l, (sk, *_rest) in enumerate(used):
+            bce, dice, comb = vals[1 + 3 * l: 4 + 3 * l]
+            if not (comb == comb and abs(comb) != float("inf")):
+                raise FloatingPointError("Segmentation loss became non-finite.")
+            logs[f"{sk}_bce"], logs[f"{sk}_dice"], logs[f"{sk}_combined"] = bce, dice, comb
+        logs["seg_total"] = vals[0]
+        return out[0], logs
+
+    # ---- torch ops (host tensors, Unified-Focal mode) --------------------------------------------------------------------------
+    def _torch_forward(self, used):
+        cfg = self.cfg
+        total = torch.zeros((), device=used[0][1].device, dtype=torch.float32)
+        logs: Dict[str, float] = {}
+        for sk, pred, tgt, w in used:
+            if tgt.shape[-2:] != pred.shape[-2:]:
+                tgt = F.interpolate(tgt.float(), size=pred.shape[-2:], mode="nearest")
+            if cfg.use_unified_focal:
+                a = _lmf(pred.float(), tgt.float(), cfg.ufl_delta, cfg.ufl_gamma)
+                b = _lmft(pred.float(), tgt.float(), cfg.ufl_delta, cfg.ufl_gamma, cfg.smooth)
+                comb = w * (cfg.ufl_lambda * a + (1.0 - cfg.ufl_lambda) * b)
+            else:
+                a = F.binary_cross_entropy_with_logits(pred, tgt.float(), reduction="mean")
+                b = _dice_probs(torch.sigmoid(pred), tgt.float(), cfg.smooth).mean()
+                comb = w * (cfg.bce_weight * a + cfg.dice_weight * b)
+            logs[f"{sk}_bce"], logs[f"{sk}_dice"] = float(a.detach()), float(b.detach())
+            if not torch.isfinite(comb):
+                raise FloatingPointError("Segmentation loss became non-finite.")
+            total = total + comb.float()
+            logs[f"{sk}_combined"] = float(comb.detach())
+        total = total * cfg.loss_lambda
+        logs["seg_total"] = float(total.detach())
+        return total, logs

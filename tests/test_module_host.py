@@ -104,7 +104,7 @@ def test_install_rebinds_the_reference_lookups():
     from mga_yolo_amd import MaskCBAM, install
     fake = {}
     for name in ("ultralytics", "ultralytics.nn", "ultralytics.nn.tasks", "mga_yolo", "mga_yolo.nn", "mga_yolo.nn.modules",
-                 "mga_yolo.nn.modules.masked_cbam"):
+                 "mga_yolo.nn.modules.masked_cbam", "mga_yolo.nn.losses", "mga_yolo.nn.losses.segmentation"):
         fake[name] = types.ModuleType(name)
     class Old:  # noqa: E306
         pass
@@ -120,6 +120,14 @@ def test_install_rebinds_the_reference_lookups():
         assert tasks.MaskCBAM is MaskCBAM and vars(tasks)["MaskCBAM"] is MaskCBAM      # globals()[m] and `m is MaskCBAM`
         built = vars(tasks)["MaskCBAM"](64)                                            # parse_model: MaskCBAM(c_in)
         assert isinstance(built, sys.modules["mga_yolo.nn.modules.masked_cbam"].MaskCBAM)   # trainer's alpha logger
+        # MGAModel.init_criterion: `from mga_yolo.nn.losses.segmentation import SegmentationLoss, SegLossConfig` at call time
+        from mga_yolo_amd import SegLossConfig, SegmentationLoss
+        losses = sys.modules["mga_yolo.nn.losses.segmentation"]
+        assert losses.SegmentationLoss is SegmentationLoss and losses.SegLossConfig is SegLossConfig
+        crit = losses.SegmentationLoss(losses.SegLossConfig(bce_weight=1.0, dice_weight=1.0, scale_weights=[1.0, 1.0, 1.0], smooth=1.0,
+                                                            loss_lambda=1.0, enabled=True))       # model.py:105-117
+        total, logs = crit({"p3": torch.zeros(1, 1, 4, 4)}, [torch.zeros(1, 1, 4, 4)])
+        assert total.shape == () and "seg_total" in logs
     finally:
         for k, v in saved.items():
             if v is None:
