@@ -215,7 +215,8 @@ __device__ __forceinline__ void handoff_publish(int* flag) {
 __device__ __forceinline__ void handoff_wait(const int* flags, int lo, int hi, int gen, int* err) {
   for (int t = lo + static_cast<int>(threadIdx.x); t <= hi; t += kBlock) {
     unsigned spins = 0;
-    while (ld_agent(flags + t) - gen < 0) {
+    // wrap-safe: the counters run for the life of ctx (2^31 calls = days of training), compare modulo 2^32
+    while (static_cast<int>(static_cast<unsigned>(ld_agent(flags + t)) - static_cast<unsigned>(gen)) < 0) {
       __builtin_amdgcn_s_sleep(4);
       if (++spins > (1u << 20)) { st_agent(err, 1); break; }   // ~1 s: give up, flag it, let the launch drain
     }

@@ -558,7 +558,7 @@ __device__ __forceinline__ void gate_body(const FwdArgs& A, const int bid, float
 #pragma unroll
   for (int j = 0; j < R; ++j) load_vec<T, VEC>(xp + static_cast<size_t>(min(ty + j * TY, g.C - 1)) * g.HW, xr[j]);
   int* flags = A.c.sync + static_cast<size_t>(b) * A.nflag;
-  const int gen = ld_agent(flags + tile) + 1;                  // the generation this call brings every flag of the level to
+  const int gen = static_cast<int>(static_cast<unsigned>(ld_agent(flags + tile)) + 1u);   // the generation this call brings every flag of the level to
 
   float* s_ca = smem;
   float* work = s_ca + ((g.C + 3) & ~3);

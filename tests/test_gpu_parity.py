@@ -386,6 +386,41 @@ def test_fused_forward_launch_equals_three_launches(F, shapes, with_mask, fused)
     check(6)
 
 
+def test_fused_forward_generation_flags_wrap_around(F):
+    """The hand-off flags count fused calls for the life of ctx; the compare is modulo 2^32, so crossing INT32_MAX is harmless."""
+    from mga_yolo_amd.plan import PyramidPlan
+    shapes = [(5, 64, 24, 24), (5, 128, 12, 12)]
+    params, cfgs = [], []
+    for l, (B, C, H, W) in enumerate(shapes):
+        p = O.Params.default_init(C, seed=l)
+        params.append((p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta))
+        cfgs.append(F.BlockConfig(hidden=p.w1.shape[0]))
+    plans = [PyramidPlan(shapes, params, cfgs, want_gmask=False, fuse_forward=f) for f in (False, True)]
+    gen = torch.Generator().manual_seed(3)
+    for l, s in enumerate(shapes):
+        x, m = torch.randn(*s, generator=gen), torch.randn(s[0], 1, s[2], s[3], generator=gen)
+        for pl in plans:
+            pl.x[l].copy_(x); pl.mask[l].copy_(m)
+    plans[0].forward()
+    for l, (B, C, H, W) in enumerate(shapes):
+        sync = plans[1].ctx_view(l)["sync"]
+        nf = B * ((H * W + 15) // 16 + 1)
+        sync[:nf] = 0x7FFFFFFE                      # every flag two calls before the wrap (as after 2^31 - 2 fused calls)
+        sync[nf + 4:] = 0x7FFFFFFE
+    for rep in range(4):
+        for l in range(len(shapes)):
+            plans[1].y[l].zero_()
+        plans[1].forward()
+        torch.cuda.synchronize()
+        for l, (B, C, H, W) in enumerate(shapes):
+            assert rel_err(plans[1].y[l], plans[0].y[l]) < 1e-6, (rep, l)
+            sync = plans[1].ctx_view(l)["sync"]
+            nf = B * ((H * W + 15) // 16 + 1)
+            assert int(sync[nf:nf + 4].abs().sum()) == 0, (rep, l, "hand-off timed out")
+    want = (0x7FFFFFFE + 4) - (1 << 32)
+    assert int(plans[1].ctx_view(0)["sync"][0]) == want
+
+
 @pytest.mark.parametrize("k", [1, 9, 11, 15])
 def test_generic_spatial_kernel_sizes(F, k):
     """spatial_k other than 3/5/7 takes the run-time-k code paths of the conv prologue, transposed conv and dWsa kernels."""

@@ -88,7 +88,7 @@ def test_device_loss_and_gradient_match_the_oracle(built_lib, B, sizes, tsize):
     assert ld.keys() == lo.keys()
     for k in lo:
         assert abs(ld[k] - lo[k]) <= 1e-5 * max(1.0, abs(lo[k])), (k, ld[k], lo[k])
-    assert abs(float(td) - float(to)) <= 1e-5 * max(1.0, abs(float(to)))
+    assert abs(float(td.detach()) - float(to.detach())) <= 1e-5 * max(1.0, abs(float(to.detach())))
     for k in preds:
         g, w = pd[k].grad.cpu(), po[k].grad
         assert float((g - w).abs().max()) <= 1e-4 * float(w.abs().max()) + 1e-9, k
