@@ -523,7 +523,7 @@ __global__ __launch_bounds__(kBlock) void k_apply(const Group<FwdArgs> G) {
 // k_gate: k_chan + k_apply in ONE pass over x with the tile RESIDENT IN REGISTERS (MGACBAM_FWD_FUSE).
 //   workgroup = (sample b, tile of TX vectors = TP contiguous pixels) x ALL channels: thread (tx, ty) keeps channels
 //   ty, ty+TY, ... (kGateR of them) of its VEC pixels in registers -- 64 KB of x per workgroup, read from HBM once.
-//     1. issue the loads; meanwhile the sample's MLP -> ca in LDS (k_chan's prologue)
+//     1. issue the loads; meanwhile wait for ca of the sample from its role workgroup (gate_role: the shared MLP, once per sample)
 //     2. per pixel max_c / mean_c of x*ca (LDS combine over the TY slices) -> planes, cidx to ctx (backward needs them anyway)
 //     3. publish the tile's plane rows; wait for the tiles whose rows the k x k window of this tile touches (in-launch
 //        hand-off, common.cuh).  Consumers only ever wait on tiles at most `span` tile-ids away and workgroups are
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(kBlock) void k_apply(const Group<FwdArgs> G) {
 //        workgroups fit on the chip many times over, and every wait is bounded anyway.
 //     4. conv + sigmoid -> sa (k_apply's prologue), y = x + alpha (x ca sa - x) straight from the registers.
 //   HBM traffic: x once + y once (2E) instead of k_chan + k_apply's 3E.
-//   LDS: [2C scratch][2h][C ca] then max(3*256*VEC combine, [3*k*k weights][3*rows*(W+k-1) planes][TP sa])
+//   LDS: [C ca] then max(3*256*VEC combine, [3*k*k weights][3*rows*(W+k-1) planes][TP sa]);  role workgroup: [2C][2h][C]
 // ---------------------------------------------------------------------------------------------
 template <typename T, int VEC, int K>
 __device__ __forceinline__ void gate_body(const FwdArgs& A, const int bid, float* smem) {
