@@ -228,7 +228,7 @@ int mgacbam_eca_backward(const mgacbam_eca_bwd_level_t* levels, int n_levels, vo
  * Multi-scale segmentation loss on the mask logits: replaces SegmentationLoss.forward in its default mode,
  * mga_yolo/nn/losses/segmentation.py:87-151 (BCEWithLogits(mean) + soft Dice per level, scale weights, loss_lambda) and its
  * autograd backward.  Targets at another resolution are gathered with F.interpolate(mode="nearest")'s index rule
- * (segmentation.py:103-110).  Unified-Focal mode (use_unified_focal) is not covered by this entry point.
+ * (segmentation.py:103-110).  use_unified_focal selects the Unified Focal mode (_lmf :44-63, _lmft :65-85, combine :114-131).
  * ------------------------------------------------------------------------------------------------ */
 #define MGASEG_MAX_LEVELS 4
 typedef struct mgaseg_level {
@@ -239,10 +239,14 @@ typedef struct mgaseg_level {
   int32_t dtype;             /* MGACBAM_F32 / F16 / BF16                                        */
   float scale_weight;        /* SegLossConfig.scale_weights[i]                                  */
 } mgaseg_level_t;
-typedef struct mgaseg_cfg { float bce_weight, dice_weight, smooth, loss_lambda; } mgaseg_cfg_t;   /* segmentation.py:10-15 */
+typedef struct mgaseg_cfg {                                   /* SegLossConfig, segmentation.py:9-21 */
+  float bce_weight, dice_weight, smooth, loss_lambda;
+  int32_t use_unified_focal;
+  float ufl_lambda, ufl_delta, ufl_gamma;
+} mgaseg_cfg_t;
 
 size_t mgaseg_ws_bytes(const mgaseg_level_t* levels, int n_levels);   /* workspace: kept from forward to backward */
-/* out (device, 1 + 3*n floats): [0] total, then per level {bce, dice, combined} (the reference's log entries) */
+/* out (device, 1 + 3*n floats): [0] total, then per level {bce | l_mf, dice | l_mft, combined} (the reference's log entries) */
 int mgaseg_forward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, void* ws, float* out, void* stream);
 /* gout: device scalar dL/d(total) */
 int mgaseg_backward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, const void* ws, const float* gout, void* stream);

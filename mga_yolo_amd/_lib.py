@@ -75,7 +75,8 @@ class SegLevel(C.Structure):                     # mgaseg_level_t
 
 
 class SegCfg(C.Structure):                       # mgaseg_cfg_t
-    _fields_ = [("bce_weight", C.c_float), ("dice_weight", C.c_float), ("smooth", C.c_float), ("loss_lambda", C.c_float)]
+    _fields_ = [("bce_weight", C.c_float), ("dice_weight", C.c_float), ("smooth", C.c_float), ("loss_lambda", C.c_float),
+                ("use_unified_focal", C.c_int32), ("ufl_lambda", C.c_float), ("ufl_delta", C.c_float), ("ufl_gamma", C.c_float)]
 
 
 SEG_MAX_LEVELS = 4

@@ -790,6 +790,7 @@ static int seg_args(const mgaseg_level_t* levels, int n, const mgaseg_cfg_t* cfg
   }
   A.start[n] = tot;
   A.w_bce = cfg->bce_weight; A.w_dice = cfg->dice_weight; A.smooth = cfg->smooth; A.lambda = cfg->loss_lambda;
+  A.ufl = cfg->use_unified_focal ? 1 : 0; A.u_lambda = cfg->ufl_lambda; A.u_delta = cfg->ufl_delta; A.u_gamma = cfg->ufl_gamma;
   A.out = nullptr; A.gout = nullptr;
   return tot;
 }

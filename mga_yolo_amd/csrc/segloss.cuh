@@ -14,6 +14,7 @@ namespace mgacbam {
 
 constexpr int kSegMaxLevels = 4;
 constexpr int kSegParts = 8;       // workgroups per sample and level
+constexpr float kSegEps = 1e-6f;   // eps of _lmf / _lmft (segmentation.py:44, 65)
 
 struct SegLevel {
   const void* logits;   // (B,1,H,W) T
@@ -29,6 +30,8 @@ struct SegArgs {
   int start[kSegMaxLevels + 1];     // workgroup ids of level l: [start[l], start[l+1])
   SegLevel lv[kSegMaxLevels];
   float w_bce, w_dice, smooth, lambda;
+  int ufl;                          // 1: Unified Focal mode (segmentation.py:44-85, 114-131): slot 0 of the sums = modified focal CE
+  float u_lambda, u_delta, u_gamma;
   float* out;                       // [0] total, then per level {bce, dice, combined}
   const float* gout;                // backward: dL/d(total), device scalar
 };
@@ -59,8 +62,16 @@ __global__ __launch_bounds__(kBlock) void k_seg_partial(const SegArgs A) {
     const int y = i / L.W;
     const float t = seg_target(L, b, y, i - y * L.W);
     const float e = expf(-fabsf(x));
-    s_bce += fmaxf(x, 0.f) - x * t + log1pf(e);              // binary_cross_entropy_with_logits, elementwise
+    const float ce = fmaxf(x, 0.f) - x * t + log1pf(e);      // binary_cross_entropy_with_logits, elementwise
     const float p = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);   // sigmoid
+    if (A.ufl) {                                             // _lmf, segmentation.py:44-52
+      const bool pos = t > 0.5f;
+      const float pt = fminf(fmaxf(pos ? p : 1.f - p, kSegEps), 1.f - kSegEps);
+      const float base = fmaxf(1.f - pt, kSegEps);
+      s_bce += powf(base, 1.f - A.u_gamma) * ce * (pos ? A.u_delta : 1.f - A.u_delta);
+    } else {
+      s_bce += ce;
+    }
     s_i += p * t; s_p += p; s_t += t;
   }
   float v[4] = {s_bce, s_i, s_p, s_t};
@@ -86,14 +97,20 @@ __global__ __launch_bounds__(kBlock) void k_seg_final(const SegArgs A) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) L.sums[b * 4 + q] = s[q];
       bce += s[0];
-      dice += 1.f - (2.f * s[1] + A.smooth) / (s[2] + s[3] + A.smooth);        // segmentation.py:38-42
+      if (A.ufl) {                                                             // _lmft, segmentation.py:65-76 (tp + fn = T, tp + fp = P)
+        const float den = fmaxf(A.u_delta * s[3] + (1.f - A.u_delta) * s[2] + A.smooth, kSegEps);
+        dice += powf(fmaxf(1.f - (s[1] + A.smooth) / den, kSegEps), A.u_gamma);
+      } else {
+        dice += 1.f - (2.f * s[1] + A.smooth) / (s[2] + s[3] + A.smooth);      // segmentation.py:38-42
+      }
     }
     bce = block_sum(bce, threadIdx.x, red);
     dice = block_sum(dice, threadIdx.x, red);
     if (threadIdx.x == 0) {
       bce /= static_cast<float>(L.B) * static_cast<float>(L.H * L.W);          // BCEWithLogitsLoss(reduction="mean")
       dice /= static_cast<float>(L.B);
-      const float comb = L.w_scale * (A.w_bce * bce + A.w_dice * dice);        // segmentation.py:134-136
+      const float comb = A.ufl ? L.w_scale * (A.u_lambda * bce + (1.f - A.u_lambda) * dice)      // segmentation.py:120
+                               : L.w_scale * (A.w_bce * bce + A.w_dice * dice);                  // segmentation.py:134-136
       A.out[1 + 3 * l] = bce; A.out[2 + 3 * l] = dice; A.out[3 + 3 * l] = comb;
       total += comb;
     }
@@ -118,14 +135,39 @@ __global__ __launch_bounds__(kBlock) void k_seg_bwd(const SegArgs A) {
   const float kb = g * A.w_bce / (static_cast<float>(L.B) * static_cast<float>(HW));
   const float kd = g * A.w_dice / static_cast<float>(L.B);
   const float num = 2.f * I + A.smooth, invD2 = 1.f / (D * D);
+  // Unified Focal: mti = (tp + s)/Du, Du = delta T + (1-delta) P + s;  M = max(1 - mti, eps)^gamma
+  const float Du_raw = A.u_delta * L.sums[b * 4 + 3] + (1.f - A.u_delta) * L.sums[b * 4 + 2] + A.smooth;
+  const float Du = fmaxf(Du_raw, kSegEps);
+  const float om = 1.f - (I + A.smooth) / Du;
+  const float dM = om > kSegEps ? -A.u_gamma * powf(om, A.u_gamma - 1.f) : 0.f;     // dM/dmti (clamp_min passes no gradient below eps)
+  const float dDu = Du_raw > kSegEps ? (1.f - A.u_delta) : 0.f;
+  const float ku = g * A.u_lambda / (static_cast<float>(L.B) * static_cast<float>(HW));
+  const float kt = g * (1.f - A.u_lambda) / static_cast<float>(L.B);
   for (int i = part * kBlock + threadIdx.x; i < HW; i += kSegParts * kBlock) {
     const float x = to_f32<T>(xp[i]);
     const int y = i / L.W;
     const float t = seg_target(L, b, y, i - y * L.W);
     const float e = expf(-fabsf(x));
     const float p = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
-    const float ddice = -(2.f * t * D - num) * invD2;
-    gp[i] = from_f32<T>(kb * (p - t) + kd * ddice * p * (1.f - p));
+    const float dp = p * (1.f - p);
+    if (A.ufl) {
+      const bool pos = t > 0.5f;
+      const float raw = pos ? p : 1.f - p;
+      const float pt = fminf(fmaxf(raw, kSegEps), 1.f - kSegEps);
+      const float dpt = (raw >= kSegEps && raw <= 1.f - kSegEps) ? (pos ? dp : -dp) : 0.f;
+      const float om_pt = 1.f - pt;
+      const float base = fmaxf(om_pt, kSegEps);
+      const float dbase = om_pt >= kSegEps ? -dpt : 0.f;
+      const float ce = fmaxf(x, 0.f) - x * t + log1pf(e);
+      const float w = pos ? A.u_delta : 1.f - A.u_delta;
+      const float a1 = 1.f - A.u_gamma;
+      const float dlmf = w * (a1 * powf(base, a1 - 1.f) * dbase * ce + powf(base, a1) * (p - t));
+      const float dmti = (t * Du - (I + A.smooth) * dDu) / (Du * Du);
+      gp[i] = from_f32<T>(ku * dlmf + kt * dM * dmti * dp);
+    } else {
+      const float ddice = -(2.f * t * D - num) * invD2;
+      gp[i] = from_f32<T>(kb * (p - t) + kd * ddice * dp);
+    }
   }
 }
 

@@ -2,10 +2,9 @@
 
 Mirrors mga_yolo/nn/losses/segmentation.py: `SegLossConfig` :9-21 and `SegmentationLoss` :23-151 (same constructor, same
 `forward(preds: {"p3"|"p4"|"p5": logits}, targets: [mask, ...]) -> (total, logs)`, same log keys, same FloatingPointError on a
-non-finite value).  Device tensors in the default mode (BCE-with-logits + soft Dice) go through the HIP entry points
+non-finite value).  Device tensors (both modes: BCE-with-logits + soft Dice, and Unified Focal) go through the HIP entry points
 `mgaseg_forward` / `mgaseg_backward` (include/mgacbam.h): two launches forward and one backward for all levels, the nearest target
-resize done inside the kernels with F.interpolate's index rule.  Host tensors, and the Unified-Focal mode (off in every shipped
-config), use the same torch ops as the reference.
+resize done inside the kernels with F.interpolate's index rule.  Host tensors use the same torch ops as the reference.
 """
 from __future__ import annotations
 
@@ -42,7 +41,7 @@ class _SegFn(torch.autograd.Function):
     """flat = n x (logits, target); returns out = [total, (bce, dice, combined) per level] on the device."""
 
     @staticmethod
-    def forward(ctx, cfg: Tuple[float, float, float, float], weights: Tuple[float, ...], *flat):
+    def forward(ctx, cfg: tuple, weights: Tuple[float, ...], *flat):
         n = len(flat) // 2
         lib = _lib.load()
         levels = (_lib.SegLevel * n)()
@@ -142,7 +141,7 @@ class SegmentationLoss(nn.Module):
             return torch.zeros((), device=first.device, dtype=torch.float32) * cfg.loss_lambda, {"seg_total": 0.0}
         on_device = all(p.is_cuda for _, p, _, _ in used)
         same_dtype = len({p.dtype for _, p, _, _ in used}) == 1 and used[0][1].dtype in _DTYPE_CODES
-        if on_device and same_dtype and not cfg.use_unified_focal and len(used) <= _lib.SEG_MAX_LEVELS:
+        if on_device and same_dtype and len(used) <= _lib.SEG_MAX_LEVELS:
             return self._device_forward(used)
         return self._torch_forward(used)
 
@@ -154,7 +153,8 @@ class SegmentationLoss(nn.Module):
             if pred.dim() != 4 or pred.shape[1] != 1 or tgt.shape[0] != pred.shape[0] or tgt.shape[1] != 1:
                 raise RuntimeError(f"SegmentationLoss: logits {tuple(pred.shape)} / target {tuple(tgt.shape)} must be (B,1,H,W)")
             flat += [pred, tgt.to(pred.device)]
-        out = _SegFn.apply((float(cfg.bce_weight), float(cfg.dice_weight), float(cfg.smooth), float(cfg.loss_lambda)),
+        out = _SegFn.apply((float(cfg.bce_weight), float(cfg.dice_weight), float(cfg.smooth), float(cfg.loss_lambda),
+                            int(bool(cfg.use_unified_focal)), float(cfg.ufl_lambda), float(cfg.ufl_delta), float(cfg.ufl_gamma)),
                            tuple(w for *_, w in used), *flat)
         vals = out.detach().cpu().tolist()                          # ONE device->host copy for every log entry
         logs: Dict[str, float] = {}
@@ -166,7 +166,7 @@ class SegmentationLoss(nn.Module):
         logs["seg_total"] = vals[0]
         return out[0], logs
 
-    # ---- torch ops (host tensors, Unified-Focal mode) --------------------------------------------------------------------------
+    # ---- torch ops (host tensors) --------------------------------------------------------------------------
     def _torch_forward(self, used):
         cfg = self.cfg
         total = torch.zeros((), device=used[0][1].device, dtype=torch.float32)

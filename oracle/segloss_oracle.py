@@ -8,8 +8,7 @@ PARITY UNPINNED by reference outputs: the reference file imports Ultralytics' LO
 needs cv2 (not installed, no network), so the class cannot be imported here and none of the reference's files hold outputs for
 it.  What pins this restatement instead: every arithmetic step is a torch op with published semantics (the same ops the
 reference calls), known-answer cases (tests/test_segloss.py) and torch autograd for the gradient.  Unified-Focal mode
-(`use_unified_focal`, off in every shipped config: configs/hyperparams/*.yaml) is restated too (`_lmf` :44-63, `_lmft` :65-85)
-so that the host path of the module can be checked, but the HIP entry point covers the default mode only.
+(`use_unified_focal`, off in every shipped config: configs/hyperparams/*.yaml) is restated too (`_lmf` :44-63, `_lmft` :65-85).
 """
 from dataclasses import dataclass
 from typing import Dict, List, Sequence, Tuple

@@ -105,7 +105,7 @@ def test_device_half_precision_logits(built_lib, dtype, tol):
     pd = {k: v.cuda().requires_grad_(True) for k, v in preds.items()}
     td, _ = SegmentationLoss(SegLossConfig())(pd, [t.cuda() for t in tg])
     td.backward()
-    assert abs(float(td) - float(to)) < 1e-5 * abs(float(to)) + 1e-6          # the sums are fp32 either way
+    assert abs(float(td.detach()) - float(to.detach())) < 1e-5 * abs(float(to.detach())) + 1e-6   # the sums are fp32 either way
     for k in preds:
         assert pd[k].grad.dtype == dtype
         w = po[k].grad
@@ -113,11 +113,29 @@ def test_device_half_precision_logits(built_lib, dtype, tol):
 
 
 @pytest.mark.gpu
-def test_device_unified_focal_and_bad_shapes(built_lib):
+@pytest.mark.parametrize("tsize,gamma,delta", [(None, 0.5, 0.6), ((64, 64), 0.75, 0.3), (None, 0.2, 0.9)])
+def test_device_unified_focal_mode(built_lib, tsize, gamma, delta):
+    """_lmf / _lmft on the device (pow, clamps and their gradient gates) == the oracle (torch ops + autograd)."""
     from mga_yolo_amd.segloss import SegLossConfig, SegmentationLoss
-    preds, tg = _data(seed=2)
-    to, lo = O.forward(preds, tg, O.SegLossConfig(use_unified_focal=True))
-    td, ld = SegmentationLoss(SegLossConfig(use_unified_focal=True))({k: v.cuda() for k, v in preds.items()}, [t.cuda() for t in tg])
-    assert all(abs(ld[k] - lo[k]) < 1e-5 for k in lo)                          # torch ops on the device in this mode
+    preds, tg = _data(B=4, tsize=tsize, seed=2)
+    preds["p4"][0] = 30.0                                   # saturated logits: pt / base clamps active
+    preds["p4"][1] = -30.0
+    kw = dict(use_unified_focal=True, ufl_gamma=gamma, ufl_delta=delta, ufl_lambda=0.4, scale_weights=(1.0, 2.0, 0.5), loss_lambda=1.3)
+    po = {k: v.clone().requires_grad_(True) for k, v in preds.items()}
+    to, lo = O.forward(po, tg, O.SegLossConfig(**kw))
+    to.backward()
+    pd = {k: v.cuda().requires_grad_(True) for k, v in preds.items()}
+    td, ld = SegmentationLoss(SegLossConfig(**kw))(pd, [t.cuda() for t in tg])
+    td.backward()
+    for k in lo:
+        assert abs(ld[k] - lo[k]) <= 1e-5 * max(1.0, abs(lo[k])), (k, ld[k], lo[k])
+    for k in preds:
+        g, w = pd[k].grad.cpu(), po[k].grad
+        assert float((g - w).abs().max()) <= 1e-4 * float(w.abs().max()) + 1e-9, k
+
+
+@pytest.mark.gpu
+def test_device_bad_shapes(built_lib):
+    from mga_yolo_amd.segloss import SegLossConfig, SegmentationLoss
     with pytest.raises(RuntimeError):
         SegmentationLoss(SegLossConfig())({"p3": torch.zeros(2, 3, 4, 4).cuda()}, [torch.zeros(2, 1, 4, 4).cuda()])
