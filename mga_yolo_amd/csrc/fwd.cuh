@@ -42,6 +42,8 @@ __device__ __forceinline__ void pool_body(const FwdArgs& A, const int bid, float
   if (!xcd_sample_part(bid, g.B, ncg, b, cg)) return;
   const int c0 = cg * CPB + ty * CPT;
   const int nv = g.HW / VEC;
+  TRACE_HWID(A.trace, blockIdx.x);
+  TRACE_MARK(A.trace, blockIdx.x, 0);
 
   const T* xr[CPT];
 #pragma unroll
@@ -105,6 +107,7 @@ __device__ __forceinline__ void pool_body(const FwdArgs& A, const int bid, float
     }
   }
 
+  TRACE_MARK(A.trace, blockIdx.x, 3);                          // sweep done
   float sums[2 * CPT + 1];
 #pragma unroll
   for (int j = 0; j < CPT; ++j) { sums[j] = sx[j]; sums[CPT + j] = sxs[j]; }
@@ -143,6 +146,12 @@ __device__ __forceinline__ void pool_body(const FwdArgs& A, const int bid, float
       A.c.den[b] = HAS_MASK ? den : 1.f;
     }
   }
+#ifdef MGACBAM_TRACE
+  TRACE_MARK(A.trace, blockIdx.x, 8);                          // reductions done, stores issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  TRACE_MARK(A.trace, blockIdx.x, 10);
+#endif
 }
 
 template <typename T, int VEC, int CPT, bool HAS_MASK>

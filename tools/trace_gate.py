@@ -15,6 +15,7 @@ import bench  # noqa: E402
 NAMES_FWD = ["start", "ca flag", "ca in LDS", "x scanned", "planes stored", "published", "neighbours", "staged", "conv", "stores issued",
              "stores done"]
 NAMES_BWD = ["start", "g_h", "terms", "loop done", "-", "-", "-", "-", "-", "-", "stores done"]   # k_bwd_apply
+NAMES_POOL = ["start", "-", "-", "sweep done", "-", "-", "-", "-", "reduced", "-", "stores done"]  # k_pool
 
 
 def main():
@@ -22,14 +23,21 @@ def main():
     nblk = 4096
     buf = torch.zeros(nblk * 16, dtype=torch.int64, device="cuda")
     which = sys.argv[1] if len(sys.argv) > 1 else "fwd"       # fwd: k_gate, bwd: k_bwd_apply
-    NAMES = NAMES_FWD if which == "fwd" else NAMES_BWD
+    NAMES = {"fwd": NAMES_FWD, "bwd": NAMES_BWD, "pool": NAMES_POOL}[which]
     S = __import__("mga_yolo_amd")._lib.BWD_STAGES
     for _ in range(3):
         plan.forward(); plan.backward()
     torch.cuda.synchronize()
     if which == "fwd":
+        plan.forward(1)
+        torch.cuda.synchronize()
         os.environ["MGACBAM_TRACE_PTR"] = str(buf.data_ptr())
-        plan.forward()
+        plan.forward(6)
+    elif which == "pool":
+        plan.backward()
+        torch.cuda.synchronize()
+        os.environ["MGACBAM_TRACE_PTR"] = str(buf.data_ptr())
+        plan.forward(1)
     else:
         plan.forward()
         plan.backward(S["reduce1"]); plan.backward(S["convT"]); plan.backward(S["reduce2"] | S["wsa"] | 64)
@@ -76,7 +84,7 @@ def main():
     life = np.stack([us(tiles[:, 0]), us(tiles[:, 10])], 1)
     for tt in range(0, int(life[:, 1].max()) + 1, 4):
         n = ((life[:, 0] <= tt) & (life[:, 1] > tt)).sum()
-        a_, b_ = (3, 8) if which == "fwd" else (2, 3)          # bwd: "loading" = prologue, "chain" = streaming loop
+        a_, b_ = {"fwd": (3, 8), "bwd": (2, 3), "pool": (3, 8)}[which]          # bwd: "loading" = prologue, "chain" = streaming loop
         nload = ((us(tiles[:, 0]) <= tt) & (us(tiles[:, a_]) > tt)).sum()
         nchain = ((us(tiles[:, a_]) <= tt) & (us(tiles[:, b_]) > tt)).sum()
         nstore = ((us(tiles[:, b_]) <= tt) & (us(tiles[:, 10]) > tt)).sum()
