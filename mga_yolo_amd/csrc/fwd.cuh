@@ -563,9 +563,10 @@ __device__ __forceinline__ void gate_body(const FwdArgs& A, const int bid, float
   const int gid = blockIdx.x;
   TRACE_HWID(A.trace, gid);
   TRACE_MARK(A.trace, gid, 0);                                 // start
-  float xr[R][VEC];                                            // the resident tile
+  Pack<T, VEC> xr[R];                                          // the resident tile, as loaded (fp16 / bf16 stay packed: VEC = 8 -> 16 B)
 #pragma unroll
-  for (int j = 0; j < R; ++j) load_vec<T, VEC>(xp + static_cast<size_t>(min(ty + j * TY, g.C - 1)) * g.HW, xr[j]);
+  for (int j = 0; j < R; ++j)
+    xr[j] = *reinterpret_cast<const Pack<T, VEC>*>(xp + static_cast<size_t>(min(ty + j * TY, g.C - 1)) * g.HW);
   int* flags = A.c.sync + static_cast<size_t>(b) * A.nflag;
   const int gen = static_cast<int>(static_cast<unsigned>(ld_agent(flags + tile)) + 1u);   // the generation this call brings every flag of the level to
 
@@ -593,7 +594,7 @@ __device__ __forceinline__ void gate_body(const FwdArgs& A, const int bid, float
       const float cac = s_ca[c];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        const float uu = xr[j][e] * cac;                       // masked_cbam.py:130
+        const float uu = to_f32<T>(xr[j].v[e]) * cac;          // masked_cbam.py:130
         vsum[e] += uu;
         if (uu > vmax[e]) { vmax[e] = uu; vidx[e] = c; }
       }
@@ -705,8 +706,9 @@ __device__ __forceinline__ void gate_body(const FwdArgs& A, const int bid, float
       float yv[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        const float u = xr[j][e] * cac;                         // masked_cbam.py:130
-        yv[e] = xr[j][e] + a * (u * sav[e] - xr[j][e]);         // masked_cbam.py:148,171
+        const float xe = to_f32<T>(xr[j].v[e]);
+        const float u = xe * cac;                               // masked_cbam.py:130
+        yv[e] = xe + a * (u * sav[e] - xe);                     // masked_cbam.py:148,171
       }
       if (active) store_vec_stream<T, VEC>(yp + static_cast<size_t>(c) * g.HW, yv, A.t.nt_stores);
     }

@@ -111,6 +111,25 @@ static int vec_of(int H, int W, int dtype = MGACBAM_F32) {
   return hw % 4 == 0 ? 4 : 1;
 }
 
+// k_gate (x-resident chan+apply): every thread keeps kGateR channels, so TY = ceil(C / kGateR) slices (power of two) and the
+// rest of the 256 threads go along H*W.  Eligible when a tile is >= kSyncPx pixels (ctx.sync has one flag per kSyncPx) and >= one
+// image row, the tiles a k x k window reaches are few (their workgroups must be co-resident: 8 ids apart per tile, common.cuh)
+// and the staged rows fit in LDS; otherwise the three-launch forward runs.
+static void gate_geometry(int C, int H, int W, int k, int VEC, Tune& t) {
+  t.gate_tx = 0; t.gate_rows = 0;
+  const int gty = pow2_ceil((C + kGateR - 1) / kGateR);
+  if (gty > kBlock || !env_int("MGACBAM_GATE", 1)) return;
+  const int gtx = kBlock / gty, TP = gtx * VEC;
+  int grows = (TP - 1) / W + 2;
+  if (grows > H) grows = H;
+  grows += k - 1;
+  const int span = ((k / 2) * W + TP - 1) / TP + 1;           // tiles reached on either side
+  const size_t lds = (3 * static_cast<size_t>(grows) * (W + k - 1) + TP + 3 * k * k + 3 * C + 64) * sizeof(float);
+  // TP >= W: a tile narrower than an image row stages k+1 full rows for a fraction of a row of outputs (measured at
+  // 1280-px inputs, C = 256/512: k_gate 220 us against 207 us for k_chan + k_apply; at >= 1.6 rows per tile it wins 18-20 %)
+  if (TP >= kSyncPx && TP >= W && 8 * span <= 256 && lds <= 48 * 1024) { t.gate_tx = gtx; t.gate_rows = grows; }
+}
+
 static Tune choose_tune(int B, int C, int H, int W, int k, int dtype = MGACBAM_F32) {
   const int HW = H * W, VEC = vec_of(H, W, dtype), nv = HW / VEC;
   Tune t;
@@ -156,19 +175,7 @@ static Tune choose_tune(int B, int C, int H, int W, int k, int dtype = MGACBAM_F
   // rest of the 256 threads go along H*W.  Eligible when a tile is >= kSyncPx pixels (ctx.sync has one flag per kSyncPx) and >= one image row,
   // the tiles a k x k window reaches are few (their workgroups must be co-resident: 8 ids apart per tile, common.cuh) and
   // the staged rows fit in LDS; otherwise the three-launch forward runs.
-  t.gate_tx = 0; t.gate_rows = 0;
-  const int gty = pow2_ceil((C + kGateR - 1) / kGateR);
-  if (gty <= kBlock && env_int("MGACBAM_GATE", 1)) {
-    const int gtx = kBlock / gty, TP = gtx * VEC;
-    int grows = (TP - 1) / W + 2;
-    if (grows > H) grows = H;
-    grows += k - 1;
-    const int span = ((k / 2) * W + TP - 1) / TP + 1;           // tiles reached on either side
-    const size_t lds = (3 * static_cast<size_t>(grows) * (W + k - 1) + TP + 3 * k * k + 3 * C + 64) * sizeof(float);
-    // TP >= W: a tile narrower than an image row stages k+1 full rows for a fraction of a row of outputs (measured at
-    // 1280-px inputs, C = 256/512: k_gate 220 us against 207 us for k_chan + k_apply; at >= 1.6 rows per tile it wins 18-20 %)
-    if (TP >= kSyncPx && TP >= W && 8 * span <= 256 && lds <= 48 * 1024) { t.gate_tx = gtx; t.gate_rows = grows; }
-  }
+  gate_geometry(C, H, W, k, VEC, t);
   return t;
 }
 
@@ -349,6 +356,21 @@ static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStre
 
   // MGACBAM_FWD_FUSE: stages 2 + 3 become ONE x-resident launch (k_gate) when every level of the group is eligible
   bool gate = (stages & MGACBAM_FWD_FUSE) && (stages & MGACBAM_FWD_CHAN) && (stages & MGACBAM_FWD_APPLY) && !sig.proj && sig.vec <= 4;
+  // fp16 / bf16: k_gate reads 16 bytes per lane (8 elements, kept packed in the registers) whatever vector width the other kernels
+  // use -- twice the pixels per tile, half the workgroups: at YOLOv8n sizes the grid then runs as ONE resident round
+  int gvec = sig.vec;
+  if (gate && sig.dtype != MGACBAM_F32 && sig.vec == 4 && env_int("MGACBAM_GATE_H8", 1)) {
+    bool ok8 = true;
+    for (int l = 0; l < n && ok8; ++l) {
+      Tune t8 = lv[l].t;
+      gate_geometry(lv[l].g.C, lv[l].g.H, lv[l].g.W, lv[l].g.k, 8, t8);
+      ok8 = (lv[l].g.HW % 8 == 0) && t8.gate_tx > 0;
+    }
+    if (ok8) {
+      gvec = 8;
+      for (int l = 0; l < n; ++l) { gate_geometry(lv[l].g.C, lv[l].g.H, lv[l].g.W, lv[l].g.k, 8, lv[l].t); G.lv[l].t = lv[l].t; }
+    }
+  }
   for (int l = 0; l < n && gate; ++l) gate = lv[l].t.gate_tx > 0;
   if (gate) for (int l = 0; l < n; ++l) { lv[l].fused = 1; G.lv[l].fused = 1; }
 
@@ -363,16 +385,16 @@ static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStre
   }
   if (gate) {
     size_t smem = 0;
-    for (int l = 0; l < n; ++l) smem = std::max(smem, gate_smem(lv[l].g, lv[l].t, sig.vec));
+    for (int l = 0; l < n; ++l) smem = std::max(smem, gate_smem(lv[l].g, lv[l].t, gvec));
     GateGroup GG;
-    const int tiles = fill([&](const FwdArgs& a) { return xcd_grid(a.g.B, gate_tiles(a.t, a.g.H, a.g.W, sig.vec)); });
+    const int tiles = fill([&](const FwdArgs& a) { return xcd_grid(a.g.B, gate_tiles(a.t, a.g.H, a.g.W, gvec)); });
     GG.g = G;
     GG.nrole = 0;
     for (int l = 0; l < n; ++l) { GG.rstart[l] = GG.nrole; GG.nrole += lv[l].g.B; }
     GG.rstart[n] = GG.nrole;
     const int grid = GG.nrole + tiles;
 #define CALL_GATE(Tt, Vv) if (sig.k == 7) LAUNCH((k_gate<Tt, Vv, 7>), grid, smem, st, GG); else LAUNCH((k_gate<Tt, Vv, 0>), grid, smem, st, GG)
-    DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_GATE);
+    DISPATCH_T_VEC(sig.dtype, gvec, CALL_GATE);
 #undef CALL_GATE
     return launch_status("k_gate");
   }

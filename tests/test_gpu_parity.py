@@ -386,6 +386,43 @@ def test_fused_forward_launch_equals_three_launches(F, shapes, with_mask, fused)
     check(6)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("shapes", [[(32, 64, 80, 80), (32, 128, 40, 40), (32, 256, 20, 20)],      # H*W % 8 == 0: 16-byte packed tiles
+                                    [(3, 64, 6, 6), (3, 32, 10, 10)]])                              # H*W % 8 != 0: 8-byte tiles
+def test_fused_forward_half_precision(F, shapes, dtype, tol):
+    """k_gate with fp16 / bf16 features (kept packed in the registers, 8 elements per lane when H*W allows) against the
+    three-launch forward and against the oracle on the same rounded inputs."""
+    from mga_yolo_amd.plan import PyramidPlan
+    params, cfgs, ps = [], [], []
+    for l, (B, C, H, W) in enumerate(shapes):
+        p = O.Params.default_init(C, seed=l)
+        p.beta.fill_(0.2)
+        ps.append(p)
+        params.append((p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta))
+        cfgs.append(F.BlockConfig(hidden=p.w1.shape[0]))
+    plans = [PyramidPlan(shapes, params, cfgs, dtype=dtype, want_gmask=False, fuse_forward=f) for f in (False, True)]
+    gen = torch.Generator().manual_seed(17)
+    data = []
+    for l, s in enumerate(shapes):
+        x = torch.randn(*s, generator=gen).to(dtype)
+        m = torch.randn(s[0], 1, s[2], s[3], generator=gen)
+        data.append((x, m))
+        for pl in plans:
+            pl.x[l].copy_(x); pl.mask[l].copy_(m)
+    for pl in plans:
+        pl.forward(); pl.forward()
+    torch.cuda.synchronize()
+    assert plans[1].gate_active()
+    for l, (x, m) in enumerate(data):
+        y_o, _ = O.forward(x.float(), m, ps[l])
+        assert rel_err(plans[1].y[l].float(), y_o) < tol, l
+        assert rel_err(plans[1].y[l].float(), plans[0].y[l].float()) < tol, l
+        a, b = plans[0].ctx_view(l), plans[1].ctx_view(l)
+        for name in ("planes", "sa", "ca"):
+            assert rel_err(b[name], a[name]) < 1e-5, (l, name)
+        assert torch.equal(a["cidx"], b["cidx"]), l
+
+
 def test_fused_forward_generation_flags_wrap_around(F):
     """The hand-off flags count fused calls for the life of ctx; the compare is modulo 2^32, so crossing INT32_MAX is harmless."""
     from mga_yolo_amd.plan import PyramidPlan
