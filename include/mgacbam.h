@@ -251,6 +251,16 @@ int mgaseg_forward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_
 /* gout: device scalar dL/d(total) */
 int mgaseg_backward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, const void* ws, const float* gout, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * ProbMaskGater: mga_yolo/nn/modules/probmaskgater.py:58-98, training mode, 'gumbel' (hard = 0) and 'hard_st'
+ * (hard = 1).  u1, u2: the two uniform tensors the reference draws with torch.rand (:53-56, 66-67), drawn by the caller the same
+ * way, so the result is a pure function of its inputs.  All tensors fp32 with n elements; msoft is kept for the backward.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mgapmg_cfg { float tau, p_min, threshold; int32_t hard; } mgapmg_cfg_t;
+int mgapmg_forward(const float* p, const float* u1, const float* u2, float* out, float* msoft, size_t n, const mgapmg_cfg_t* cfg,
+                   void* stream);
+int mgapmg_backward(const float* p, const float* msoft, const float* gout, float* gp, size_t n, const mgapmg_cfg_t* cfg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,11 @@ class SegCfg(C.Structure):                       # mgaseg_cfg_t
 
 SEG_MAX_LEVELS = 4
 
+
+class PmgCfg(C.Structure):                       # mgapmg_cfg_t
+    _fields_ = [("tau", C.c_float), ("p_min", C.c_float), ("threshold", C.c_float), ("hard", C.c_int32)]
+
+
 SYMBOLS = {
     "mgacbam_abi_version": (C.c_int, []),
     "mgacbam_last_error": (C.c_char_p, []),
@@ -100,6 +105,8 @@ SYMBOLS = {
     "mgaseg_ws_bytes": (C.c_size_t, [C.POINTER(SegLevel), C.c_int]),
     "mgaseg_forward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgaseg_backward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgapmg_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_size_t, C.POINTER(PmgCfg), C.c_void_p]),
+    "mgapmg_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_size_t, C.POINTER(PmgCfg), C.c_void_p]),
 }
 
 _lib = None

@@ -16,6 +16,7 @@
 #include "common.cuh"
 #include "eca.cuh"
 #include "segloss.cuh"
+#include "gater.cuh"
 #include "fwd.cuh"
 
 using namespace mgacbam;
@@ -847,6 +848,40 @@ extern "C" int mgaseg_backward(const mgaseg_level_t* levels, int n, const mgaseg
     default: LAUNCH(k_seg_bwd<bf16_t>, grid, 0, st, A); break;
   }
   if (int e = launch_status("k_seg_bwd")) return e;
+  g_err[0] = 0;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ProbMaskGater
+// ------------------------------------------------------------------------------------------------
+static int pmg_args(size_t n, const mgapmg_cfg_t* cfg, GaterArgs& A) {
+  if (!cfg) return fail(MGACBAM_E_NULL, "gater: cfg is NULL");
+  if (n < 1 || !(cfg->tau > 0.f)) return fail(MGACBAM_E_SHAPE, "gater: n=%zu tau=%g", n, cfg->tau);
+  A.n = n; A.inv_tau = 1.f / cfg->tau; A.p_min = cfg->p_min; A.threshold = cfg->threshold; A.hard = cfg->hard ? 1 : 0;
+  A.p = A.u1 = A.u2 = A.gout = nullptr; A.out = A.msoft = A.gp = nullptr;
+  return 0;
+}
+static unsigned pmg_grid(size_t n) { const size_t g = (n + kBlock - 1) / kBlock; return static_cast<unsigned>(g > 2048 ? 2048 : g); }
+extern "C" int mgapmg_forward(const float* p, const float* u1, const float* u2, float* out, float* msoft, size_t n,
+                              const mgapmg_cfg_t* cfg, void* stream) {
+  if (!p || !u1 || !u2 || !out || !msoft) return fail(MGACBAM_E_NULL, "gater: NULL pointer");
+  GaterArgs A;
+  if (int e = pmg_args(n, cfg, A)) return e;
+  A.p = p; A.u1 = u1; A.u2 = u2; A.out = out; A.msoft = msoft;
+  hipLaunchKernelGGL(k_pmg_fwd, dim3(pmg_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), A);
+  if (int e = launch_status("k_pmg_fwd")) return e;
+  g_err[0] = 0;
+  return 0;
+}
+extern "C" int mgapmg_backward(const float* p, const float* msoft, const float* gout, float* gp, size_t n, const mgapmg_cfg_t* cfg,
+                               void* stream) {
+  if (!p || !msoft || !gout || !gp) return fail(MGACBAM_E_NULL, "gater: NULL pointer");
+  GaterArgs A;
+  if (int e = pmg_args(n, cfg, A)) return e;
+  A.p = p; A.msoft = const_cast<float*>(msoft); A.gout = gout; A.gp = gp;
+  hipLaunchKernelGGL(k_pmg_bwd, dim3(pmg_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), A);
+  if (int e = launch_status("k_pmg_bwd")) return e;
   g_err[0] = 0;
   return 0;
 }

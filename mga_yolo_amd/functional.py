@@ -347,3 +347,42 @@ def resize_nearest(src: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
         _lib.check(lib.mgacbam_resize_nearest(s.data_ptr(), dst.data_ptr(), planes, in_h, in_w, out_h, out_w,
                                               torch.cuda.current_stream(s.device).cuda_stream), "mgacbam_resize_nearest")
     return dst
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ProbMaskGater: gumbel / hard_st sampling as one launch; the uniforms come from the caller
+# ---------------------------------------------------------------------------------------------------------
+class _GaterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, u1, u2, tau: float, p_min: float, threshold: float, hard: bool):
+        lib = _lib.load()
+        pc, a, b = (_ready(t) for t in (p, u1, u2))
+        if pc.dtype != torch.float32 or a.dtype != torch.float32 or b.dtype != torch.float32 or a.shape != pc.shape or b.shape != pc.shape:
+            raise RuntimeError("prob_mask_gate: p, u1, u2 must be fp32 tensors of one shape")
+        out, msoft = torch.empty_like(pc), torch.empty_like(pc)
+        cfg = _lib.PmgCfg(float(tau), float(p_min), float(threshold), int(bool(hard)))
+        with torch.cuda.device(pc.device):
+            _lib.check(lib.mgapmg_forward(pc.data_ptr(), a.data_ptr(), b.data_ptr(), out.data_ptr(), msoft.data_ptr(), pc.numel(),
+                                          C.byref(cfg), torch.cuda.current_stream(pc.device).cuda_stream), "mgapmg_forward")
+        ctx.save_for_backward(pc, msoft)
+        ctx.cfg = (float(tau), float(p_min), float(threshold), int(bool(hard)))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pc, msoft = ctx.saved_tensors
+        lib = _lib.load()
+        g = _ready(gout.to(torch.float32))
+        gp = torch.empty_like(pc)
+        cfg = _lib.PmgCfg(*ctx.cfg)
+        with torch.cuda.device(pc.device):
+            _lib.check(lib.mgapmg_backward(pc.data_ptr(), msoft.data_ptr(), g.data_ptr(), gp.data_ptr(), pc.numel(), C.byref(cfg),
+                                           torch.cuda.current_stream(pc.device).cuda_stream), "mgapmg_backward")
+        return gp, None, None, None, None, None, None
+
+
+def prob_mask_gate(p: torch.Tensor, u1: torch.Tensor, u2: torch.Tensor, tau: float = 1.0, p_min: float = 0.0, threshold: float = 0.5,
+                   hard: bool = False) -> torch.Tensor:
+    """Gumbel-sigmoid gate of ProbMaskGater for device tensors: max(clamp(p,0,1), p_min) -> sigmoid((logit + logistic(u1,u2)) / tau),
+    thresholded with a straight-through gradient when ``hard``.  u1, u2: uniform draws, as torch.rand gives them."""
+    return _GaterFn.apply(p, u1, u2, tau, p_min, threshold, hard)

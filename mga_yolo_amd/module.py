@@ -20,17 +20,18 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .functional import BlockConfig, EcaConfig, mask_cbam, mask_eca
+from .functional import BlockConfig, EcaConfig, mask_cbam, mask_eca, prob_mask_gate
 
 _GATER_MODES = ("deterministic", "gumbel", "hard_st", "bernoulli_detach")
 
 
 class ProbMaskGater(nn.Module):
     """Stochastic gate applied to the mask BEFORE the block when ``MGA_PROB_MODE`` is set
-    (reference mga_yolo/nn/modules/probmaskgater.py:8-98).  RNG-dependent, so it stays in PyTorch upstream of the kernels
-    (SURVEY 8a row a9): the input is clamped to [0,1] (note: applied to whatever the mask head emits, logits included),
-    eval / 'deterministic' return that, 'gumbel' adds logistic noise in logit space, 'hard_st' thresholds with a
-    straight-through gradient, 'bernoulli_detach' samples without gradient."""
+    (reference mga_yolo/nn/modules/probmaskgater.py:8-98): the input is clamped to [0,1] (note: applied to whatever the mask
+    head emits, logits included), eval / 'deterministic' return that, 'gumbel' adds logistic noise in logit space, 'hard_st'
+    thresholds with a straight-through gradient, 'bernoulli_detach' samples without gradient.  The random numbers always come
+    from torch's generator, drawn exactly as the reference draws them; for device tensors in the two Gumbel modes everything
+    after the draws is ONE HIP launch (``functional.prob_mask_gate``) instead of ~14 elementwise kernels."""
 
     def __init__(self, mode: str = "gumbel", tau: float = 1.0, p_min: float = 0.0, threshold: float = 0.5,
                  seed: Optional[int] = None):
@@ -62,6 +63,12 @@ class ProbMaskGater(nn.Module):
     def forward(self, p: torch.Tensor) -> torch.Tensor:
         if p.dim() == 3:
             p = p.unsqueeze(1)
+        if p.is_cuda and self.training and self.mode in ("gumbel", "hard_st"):
+            p = p.float()
+            gen = self._generator(p.device)
+            u1 = torch.rand(p.shape, dtype=p.dtype, device=p.device, generator=gen)
+            u2 = torch.rand(p.shape, dtype=p.dtype, device=p.device, generator=gen)
+            return prob_mask_gate(p, u1, u2, self.tau, self.p_min, self.threshold, hard=self.mode == "hard_st")
         p = p.float().clamp(0.0, 1.0)
         if self.p_min > 0:
             p = p.clamp_min(self.p_min)

@@ -15,7 +15,7 @@ HEADER = os.path.join(ROOT, "include", "mgacbam.h")
 def declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(mga(?:cbam|seg)_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(mga(?:cbam|seg|pmg)_\w+)\s*\(", src)))
 
 
 def test_header_declares_the_expected_entry_points():
