@@ -15,6 +15,9 @@
  *   - return value: 0 = ok, <0 = argument error (MGACBAM_E_*), >0 = hipError_t from a launch.
  *   - tensors are dense NCHW; `dtype` selects the element type of x / y / gy / gx (mask, parameters,
  *     every accumulator and every saved statistic are fp32).
+ *
+ * Entry-point families: mgacbam_*  MaskCBAM (the hot path) + mgacbam_eca_* MaskECA + mgacbam_resize_nearest;
+ *                       mgaseg_*   multi-scale segmentation loss;   mgapmg_*  ProbMaskGater's Gumbel gate.
  */
 #ifndef MGACBAM_H_
 #define MGACBAM_H_
@@ -26,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MGACBAM_ABI_VERSION 7
+#define MGACBAM_ABI_VERSION 8
 #define MGACBAM_MAX_LEVELS 8          /* P3/P4/P5 need 3 */
 
 enum { MGACBAM_F32 = 0, MGACBAM_F16 = 1, MGACBAM_BF16 = 2 };
