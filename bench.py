@@ -50,6 +50,7 @@ WORKLOADS = {
 # algorithmic bytes of each HBM-bound kernel in units of E*w (feature-sized tensors it must read or write once)
 FWD_KERNEL_E = {"pool": 1, "chan": 1, "apply": 2, "gate": 2}   # k_gate = chan + apply with x resident: read x once, write y
 BWD_KERNEL_E = {"reduce1": 2, "reduce2": 1, "apply": 3}
+KERNEL_SYMBOL_FOLD = {"bwd.reduce1": "k_bwd_reduce1_fold"}
 KERNEL_SYMBOL = {"fwd.pool": "k_pool", "fwd.chan": "k_chan", "fwd.apply": "k_apply", "fwd.gate": "k_gate", "bwd.reduce1": "k_bwd_reduce1",
                  "bwd.reduce2": "k_bwd_reduce2", "bwd.apply": "k_bwd_apply", "bwd.convT": "k_bwd_convT"}
 
@@ -109,10 +110,16 @@ def time_kernels(plan, reps):
         fwd += [("fwd.gate", plan.forward, Fs["chan"] | Fs["apply"])]     # one x-resident launch (plan adds FWD_FUSE)
     else:
         fwd += [("fwd.chan", plan.forward, Fs["chan"]), ("fwd.apply", plan.forward, Fs["apply"])]
-    seq = fwd + [("bwd.reduce1", plan.backward, Bs["reduce1"]), ("bwd.convT", plan.backward, Bs["convT"]),
+    folded = plan.fold_active()
+    if folded:                   # the transposed conv rides at the end of the k_bwd_reduce1 launch (one launch, as in the real step)
+        bwd = [("bwd.reduce1", plan.backward, Bs["reduce1"] | Bs["convT"] | _lib.BWD_FOLD)]
+    else:
+        bwd = [("bwd.reduce1", plan.backward, Bs["reduce1"]), ("bwd.convT", plan.backward, Bs["convT"])]
+    fold_bit = _lib.BWD_FOLD if plan.fold_backward else 0
+    seq = fwd + bwd + [
            # the two fused launches: streaming workgroups + role workgroups (dWsa partials / parameter gradients)
            ("bwd.reduce2", plan.backward, Bs["reduce2"] | Bs["wsa"] | _lib.BWD_FUSE),
-           ("bwd.apply", plan.backward, Bs["params"] | Bs["apply"] | _lib.BWD_FUSE)]
+           ("bwd.apply", plan.backward, Bs["params"] | Bs["apply"] | _lib.BWD_FUSE | fold_bit)]
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(seq) + 1)] for _ in range(reps)]
     for _ in range(3):
         for _, fn, mask in seq:
@@ -142,6 +149,7 @@ def time_kernels(plan, reps):
     pad = max(0.0, (sum(out.values()) - t_outer) / len(seq))     # (t_outer has the same number of launches)
     out = {k: max(v - pad, 0.0) for k, v in out.items()}
     out["_event_pad_us"] = pad
+    out["_folded"] = folded
     return out
 
 
@@ -269,10 +277,11 @@ def main():
     w = 4 if args.dtype == "f32" else 2
     kernels = {}
     event_pad = kt.pop("_event_pad_us")
+    symbols = dict(KERNEL_SYMBOL, **(KERNEL_SYMBOL_FOLD if kt.pop("_folded") else {}))
     for name, us in kt.items():
         side, k = name.split(".")
         mult = (FWD_KERNEL_E if side == "fwd" else BWD_KERNEL_E).get(k)
-        ent = dict(us=round(us, 2), launches=1, symbol=KERNEL_SYMBOL[name])
+        ent = dict(us=round(us, 2), launches=1, symbol=symbols[name])
         if mult:
             ent["alg_bytes"] = mult * E * w
             ent["GBps"] = round(mult * E * w / us / 1e3, 1)
@@ -282,10 +291,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")   # PMC-derived HBM bytes (collected with rocprofv3, see profiles/)
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.workload, {}).get(KERNEL_SYMBOL[dom])
+            traffic = json.load(open(tpath)).get(args.workload, {}).get(symbols[dom])
         except Exception:
             traffic = None
-    roofline = dict(bound="hbm", kernel=KERNEL_SYMBOL[dom], stage=dom, achieved=kernels[dom]["GBps"], peak=HBM_PEAK_GBPS, unit="GB/s",
+    roofline = dict(bound="hbm", kernel=symbols[dom], stage=dom, achieved=kernels[dom]["GBps"], peak=HBM_PEAK_GBPS, unit="GB/s",
                     frac=round(kernels[dom]["GBps"] / HBM_PEAK_GBPS, 4), traffic=traffic,
                     alg_bytes_per_launch=kernels[dom]["alg_bytes"], us=kernels[dom]["us"],
                     note="one launch covers P3+P4+P5; duration = mean elapsed time between an event recorded before and one after the launch, on the launch stream, with the step issued in order")

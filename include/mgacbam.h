@@ -121,7 +121,7 @@ typedef struct mgacbam_ctx_layout {
   int64_t cidx;     /* (B,HW)   int32: first arg-max channel of u          masked_cbam.py:135 */
   int64_t sa;       /* (B,HW)   spatial gate                              masked_cbam.py:147 */
   int64_t proj;     /* (B,hid,HW) W1-projection of x, only when hid <= MGACBAM_PROJ_MAX_HIDDEN (else empty)  */
-  int64_t sync;     /* int32: (B, ceil(HW/16)+1) tile generation flags of MGACBAM_FWD_FUSE (see there), 4 status words, (B) ca flags */
+  int64_t sync;     /* int32: (B, ceil(HW/16)+1) tile generation flags of MGACBAM_FWD_FUSE (see there), 4 status words, (B) ca flags, (B, ceil(HW/16)+1) MGACBAM_BWD_FOLD tile flags */
   int64_t total;    /* == mgacbam_ctx_bytes()                                                 */
 } mgacbam_ctx_layout_t;
 
@@ -172,7 +172,13 @@ enum {
   MGACBAM_BWD_PARAMS = 31,    /* every stage the parameter gradients depend on, as separate launches: a data-parallel
                                  caller starts its all-reduce after this and overlaps it with MGACBAM_BWD_INPUTS     */
   MGACBAM_BWD_INPUTS = 32,    /* the stage only the input gradients depend on                   */
-  MGACBAM_BWD_ALL = 127       /* everything, fused: what mgacbam_backward() runs                */
+  MGACBAM_BWD_ALL = 127,
+  MGACBAM_BWD_FOLD = 128      /* with REDUCE1 + CONVT: the transposed-conv tiles run as the LAST workgroups of the REDUCE1 launch and
+                                 pick the g_pre rows up inside the launch (one flag per REDUCE1 tile in ctx.sync; contract as
+                                 MGACBAM_FWD_FUSE: the caller zero-filled ctx[sync .. total) once).  With APPLY: that launch
+                                 clears the flags again -- a folded REDUCE1 must be followed by an APPLY carrying this bit
+                                 before the next one on the same ctx (mgacbam_backward_stages(MGACBAM_BWD_ALL | MGACBAM_BWD_FOLD)
+                                 does both).  Not part of MGACBAM_BWD_ALL: mgacbam_backward() works on an un-zeroed ctx      */
 };
 int mgacbam_forward_stages(const mgacbam_fwd_level_t* levels, int n_levels, int stages, void* stream);
 int mgacbam_backward_stages(const mgacbam_bwd_level_t* levels, int n_levels, int stages, void* stream);

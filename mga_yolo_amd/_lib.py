@@ -17,6 +17,7 @@ BWD_STAGES = dict(reduce1=1, convT=2, reduce2=4, wsa=8, params=16, apply=32)
 BWD_FUSE = 64
 FWD_SAVE_PROJ, BWD_HAVE_PROJ, PROJ_MAX_HIDDEN = 1, 1, 4
 FWD_ALL, BWD_PARAMS, BWD_INPUTS, BWD_ALL = 7, 31, 32, 127
+BWD_FOLD = 128   # with BWD_ALL: transposed conv folded into the k_bwd_reduce1 launch (ctx.sync zero-filled once by the caller)
 FWD_FUSE = 8   # with FWD_ALL: one launch, in-launch hand-off through ctx.sync (caller zero-fills it once)
 
 _c_float_p = C.POINTER(C.c_float)

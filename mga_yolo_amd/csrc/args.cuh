@@ -24,7 +24,7 @@ struct CtxPtrs {
   float* h_avg; float* h_mx; float* ca;
   float* planes; int* cidx; float* sa;
   float* proj;     // (B, hidden, HW) when hidden <= kProjMax
-  int* sync;       // in-launch hand-off state: [B][nflag] tile generation flags, 4 status words ([0] = time-out), [B] per-sample ca generation flags
+  int* sync;       // in-launch hand-off state: [B][nflag] tile generation flags, 4 status words ([0] = time-out), [B] per-sample ca generation flags, [B][nflag] k_bwd_reduce1 tile flags (MGACBAM_BWD_FOLD; 0 between calls)
 };
 
 struct ParamPtrs { const float* w1; const float* b1; const float* w2; const float* b2; const float* wsa; const float* beta; };
@@ -73,6 +73,10 @@ struct BwdArgs {
   int nwsa;     // k_bwd_wsa tiles of this level: one dWsa partial each
   int npg;      // parameter-gradient workgroups of this level (k_bwd_params roles)
   int ncg;      // channel groups per sample of k_bwd_reduce2
+  int nflag;    // flags per sample in c.sync
+  int bflag0;   // first backward hand-off flag in c.sync (ints): [B][nflag], one per k_bwd_reduce1 tile
+  int vec;      // elements per lane of the tile kernels (TP = chan_tx * vec pixels per tile)
+  int fold;     // MGACBAM_BWD_FOLD active for this call: k_bwd_apply clears the flags again
   long long* trace;   // MGACBAM_TRACE builds only (tools/trace_gate.py), else nullptr
 };
 

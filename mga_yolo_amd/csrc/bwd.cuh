@@ -41,7 +41,7 @@ namespace mgacbam {
 // ---------------------------------------------------------------------------------------------
 // k_bwd_reduce1     (thread layout of k_chan: one H*W vector per lane, rows take channel slices; TX <= 64)
 // ---------------------------------------------------------------------------------------------
-template <typename T, int VEC>
+template <typename T, int VEC, bool FOLD = false>   // FOLD: the transposed-conv tiles ride at the end of this launch (k_bwd_reduce1, ROLES)
 __device__ __forceinline__ void bwd_reduce1_body(const BwdArgs& A, const int bid, float* smem) {
   const Geo& g = A.g;
   const int tid = threadIdx.x;
@@ -105,8 +105,15 @@ __device__ __forceinline__ void bwd_reduce1_body(const BwdArgs& A, const int bid
     float gpre[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) gpre[e] = a * accp[e] * sav[e] * (1.f - sav[e]);   // g_sa * sigmoid'
-    store_vec<float, VEC>(A.s.gpre + static_cast<size_t>(b) * g.HW + static_cast<size_t>(i) * VEC, gpre);
+    float* gq = A.s.gpre + static_cast<size_t>(b) * g.HW + static_cast<size_t>(i) * VEC;
+    if (FOLD) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) st_agent(gq + e, gpre[e]);   // consumed inside this launch by the transposed-conv roles
+    } else {
+      store_vec<float, VEC>(gq, gpre);
+    }
   }
+  if (FOLD) handoff_publish(A.c.sync + A.bflag0 + static_cast<size_t>(b) * A.nflag + tile);   // this tile's g_pre rows are out
 }
 
 template <typename T, int VEC>
@@ -122,12 +129,10 @@ __global__ __launch_bounds__(kBlock) void k_bwd_reduce1(const Group<BwdArgs> G) 
 //   flipped kernel).  Tile = TH rows x TW columns of one sample, g_pre tile + halo in LDS (one load batch), 4 adjacent
 //   pixels x 3 planes per thread.  On the critical path between k_bwd_reduce1 and k_bwd_reduce2, so it does nothing else.
 // ---------------------------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(kBlock) void k_bwd_convT(const Group<BwdArgs> G) {
-  extern __shared__ __align__(16) float smem[];
-  int local;
-  const int lvl = find_level(G, blockIdx.x, local);
-  const BwdArgs& A = G.lv[lvl];
+// COH: g_pre was published inside this launch by k_bwd_reduce1's tile workgroups (lower ids): wait (bounded) for the tiles whose
+// pixels the window touches, then read it with agent-scope loads
+template <int K, bool COH>
+__device__ __forceinline__ void bwd_convT_body(const BwdArgs& A, const int local, float* smem) {
   const Geo& g = A.g;
   const int k = K ? K : g.k;
   const ConvTile c = conv_tile(g, A.t, k, local, A.t.conv_th);
@@ -136,7 +141,13 @@ __global__ __launch_bounds__(kBlock) void k_bwd_convT(const Group<BwdArgs> G) {
   float* tg = smem + ((3 * k * k + 3) & ~3);   // g_pre tile + halo
   for (int i = tid; i < 3 * k * k; i += kBlock) wts[i] = A.p.wsa[i];
   const float* gpre = A.s.gpre + static_cast<size_t>(c.b) * g.HW;
-  stage_window<8>(tg, 1, c.PH, c.PW, c.y0 - c.pad, c.x0 - c.pad, g, [&](int, int off) { return gpre[off]; });
+  if (COH) {
+    const int TP = A.t.chan_tx * A.vec;                        // pixels per k_bwd_reduce1 tile
+    const int ra = max(c.y0 - c.pad, 0), rb = min(c.y0 + c.TH - 1 + c.pad, g.H - 1);
+    handoff_wait(A.c.sync + A.bflag0 + static_cast<size_t>(c.b) * A.nflag, (ra * g.W) / TP, ((rb + 1) * g.W - 1) / TP, 1,
+                 A.c.sync + static_cast<size_t>(g.B) * A.nflag);
+  }
+  stage_window<8>(tg, 1, c.PH, c.PW, c.y0 - c.pad, c.x0 - c.pad, g, [&](int, int off) { return COH ? ld_agent(gpre + off) : gpre[off]; });
   __syncthreads();
   const int TWQ = A.t.conv_twq;
   const int py = tid / TWQ, q = tid - py * TWQ;
@@ -190,6 +201,32 @@ __global__ __launch_bounds__(kBlock) void k_bwd_convT(const Group<BwdArgs> G) {
       }
     }
   }
+}
+
+template <int K>
+__global__ __launch_bounds__(kBlock) void k_bwd_convT(const Group<BwdArgs> G) {
+  extern __shared__ __align__(16) float smem[];
+  int local;
+  const int lvl = find_level(G, blockIdx.x, local);
+  bwd_convT_body<K, false>(G.lv[lvl], local, smem);
+}
+
+// k_bwd_reduce1 with the transposed conv folded in (MGACBAM_BWD_FOLD): grid of a level = [tile workgroups][nconv conv tiles LAST].
+// The conv tiles start as the streaming workgroups retire and need only the g_pre rows of a few tiles each, so most of the
+// latency-bound conv overlaps the streaming tail and one launch boundary disappears.  Flags: one per k_bwd_reduce1 tile in ctx.sync,
+// 0 before the call (zero-filled by the caller once), set here, cleared again by k_bwd_apply of the same call.
+template <typename T, int VEC, int K>
+__global__ __launch_bounds__(kBlock) void k_bwd_reduce1_fold(const Group<BwdArgs> G) {
+  extern __shared__ __align__(16) float smem[];
+  int local;
+  const int l = find_level(G, blockIdx.x, local);
+  const BwdArgs& A = G.lv[l];
+  const int tiles = ((A.g.B + 7) / 8) * 8 * A.nt;
+  if (local >= tiles) {
+    if (local - tiles < A.nconv) bwd_convT_body<K, true>(A, local - tiles, smem);
+    return;
+  }
+  bwd_reduce1_body<T, VEC, true>(A, local, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -537,6 +574,8 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
   const T* xp = static_cast<const T*>(A.x) + base;
   const T* gp = static_cast<const T*>(A.gy) + base;
   T* op = static_cast<T*>(A.gx) + base;
+  if (A.fold && tile == 0)                                     // re-arm MGACBAM_BWD_FOLD's flags of this sample for the next call
+    for (int t = tid; t < ntile; t += kBlock) A.c.sync[A.bflag0 + static_cast<size_t>(b) * A.nflag + t] = 0;
   const float a = softplusf_(*A.p.beta);
   const float N = static_cast<float>(g.HW);
   const bool has_mask = A.mask != nullptr;

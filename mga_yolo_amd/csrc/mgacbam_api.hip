@@ -72,7 +72,7 @@ static void ctx_layout(int B, int C, int H, int W, int hidden, mgacbam_ctx_layou
   L->cidx = take(static_cast<size_t>(B) * HW);
   L->sa = take(static_cast<size_t>(B) * HW);
   L->proj = take(hidden <= MGACBAM_PROJ_MAX_HIDDEN ? static_cast<size_t>(B) * hidden * HW : 0);
-  L->sync = take(static_cast<size_t>(B) * sync_flags(HW) + 4 + B);
+  L->sync = take(2 * static_cast<size_t>(B) * sync_flags(HW) + 4 + B);
   L->total = static_cast<int64_t>(o);
 }
 
@@ -496,6 +496,10 @@ static int backward_args(const mgacbam_bwd_level_t& L, BwdArgs& A, Sig& sig) {
   A.nwsa = A.g.B * wsa_tiles(A.t, A.g.H, A.g.W);
   A.npg = params_blocks(A.g);
   A.ncg = 0;
+  A.nflag = static_cast<int>(sync_flags(static_cast<size_t>(L.H) * L.W));
+  A.bflag0 = L.B * A.nflag + 4 + L.B;
+  A.vec = VEC;
+  A.fold = 0;
   { const char* tp = getenv("MGACBAM_TRACE_PTR"); A.trace = (tp && *tp) ? reinterpret_cast<long long*>(strtoull(tp, nullptr, 0)) : nullptr; }
   const int proj = (L.flags & MGACBAM_BWD_HAVE_PROJ) && L.gmask != nullptr;
   A.g.proj_h = (proj && L.p.hidden <= MGACBAM_PROJ_MAX_HIDDEN) ? L.p.hidden : 0;
@@ -515,7 +519,24 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
   }
   auto fill = [&](auto blocks_of) { int tot = 0; for (int l = 0; l < n; ++l) { G.start[l] = tot; tot += blocks_of(lv[l]); } G.start[n] = tot; return tot; };
 
-  if (stages & MGACBAM_BWD_REDUCE1) {  // 1. per-(b,c) and per-pixel reductions of gy*x
+  // MGACBAM_BWD_FOLD: transposed conv as trailing role workgroups of the k_bwd_reduce1 launch (whole backward in this call, a tile at
+  // least one image row and at least kSyncPx pixels -- one flag per tile in ctx.sync -- and few tiles per conv window)
+  bool fold = (stages & MGACBAM_BWD_FOLD) && (stages & MGACBAM_BWD_REDUCE1) && (stages & MGACBAM_BWD_CONVT) && env_int("MGACBAM_BWD_FOLD", 1);
+  for (int l = 0; l < n && fold; ++l) {
+    const int TP = lv[l].t.chan_tx * sig.vec;
+    fold = TP >= kSyncPx && TP >= lv[l].g.W && 8 * (((lv[l].t.conv_th + lv[l].g.k) * lv[l].g.W + TP - 1) / TP + 1) <= 512;
+  }
+  if (stages & MGACBAM_BWD_FOLD) for (int l = 0; l < n; ++l) { lv[l].fold = 1; G.lv[l].fold = 1; }   // k_bwd_apply clears the flags
+  if (fold) {
+    size_t smem = 0;
+    for (int l = 0; l < n; ++l) smem = std::max({smem, reduce1_smem(lv[l].g, sig.vec), convT_smem(lv[l].t, sig.k)});
+    const int grid = fill([&](const BwdArgs& a) { return xcd_grid(a.g.B, a.nt) + pad8(a.nconv); });
+#define CALL_R1F(Tt, Vv) if (sig.k == 7) LAUNCH((k_bwd_reduce1_fold<Tt, Vv, 7>), grid, smem, st, G); else LAUNCH((k_bwd_reduce1_fold<Tt, Vv, 0>), grid, smem, st, G)
+    DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_R1F);
+#undef CALL_R1F
+    if (int e = launch_status("k_bwd_reduce1_fold")) return e;
+  }
+  if ((stages & MGACBAM_BWD_REDUCE1) && !fold) {  // 1. per-(b,c) and per-pixel reductions of gy*x
     size_t smem = 0;
     for (int l = 0; l < n; ++l) smem = std::max(smem, reduce1_smem(lv[l].g, sig.vec));
     const int grid = fill([&](const BwdArgs& a) { return xcd_grid(a.g.B, a.nt); });
@@ -524,7 +545,7 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
 #undef CALL_R1
     if (int e = launch_status("k_bwd_reduce1")) return e;
   }
-  if (stages & MGACBAM_BWD_CONVT) {  // 2. transposed conv
+  if ((stages & MGACBAM_BWD_CONVT) && !fold) {  // 2. transposed conv
     size_t smem = 0;
     for (int l = 0; l < n; ++l) smem = std::max(smem, convT_smem(lv[l].t, sig.k));
     const int grid = fill([&](const BwdArgs& a) { return a.nconv; });

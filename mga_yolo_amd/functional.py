@@ -33,6 +33,8 @@ _DTYPES = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _li
 _USE_PROJ = bool(int(os.environ.get("MGACBAM_PROJ", "0")))
 # k_chan + k_apply as ONE x-resident launch (k_gate, MGACBAM_FWD_FUSE); MGACBAM_FUSE_FWD=0 restores the three-launch forward
 _FUSE_FWD = bool(int(os.environ.get("MGACBAM_FUSE_FWD", "1")))
+# transposed conv folded into the k_bwd_reduce1 launch (MGACBAM_BWD_FOLD); needs the zero-filled ctx tail the fused forward sets up
+_FOLD_BWD = _FUSE_FWD and bool(int(os.environ.get("MGACBAM_FOLD_BWD", "1")))
 SLOTS = 8  # tensors per level in the flat argument list: x, mask, w1, b1, w2, b2, wsa, beta
 
 
@@ -163,7 +165,8 @@ class _PyramidFn(torch.autograd.Function):
                 gmask = gmask.reshape(mshape).to(mdtype)
             grads += [gx, gmask, *pg]
         with torch.cuda.device(dev):
-            _lib.check(lib.mgacbam_backward(levels, n, torch.cuda.current_stream(dev).cuda_stream), "mgacbam_backward")
+            stages = _lib.BWD_ALL | (_lib.BWD_FOLD if _FOLD_BWD else 0)
+            _lib.check(lib.mgacbam_backward_stages(levels, n, stages, torch.cuda.current_stream(dev).cuda_stream), "mgacbam_backward_stages")
         del hold
         return tuple(grads)
 
@@ -214,7 +217,7 @@ def ctx_views(cbuf: torch.Tensor, B, Cc, H, W, hidden) -> dict:
     if hidden <= _lib.PROJ_MAX_HIDDEN:
         shapes["proj"] = (B, hidden, HW)
     nflag = (HW + 15) // 16 + 1
-    shapes["sync"] = (B * nflag + 4 + B,)   # FWD_FUSE hand-off: (B, nflag) generation flags, [time-out flag, 3 spare], (B) arrival counters
+    shapes["sync"] = (2 * B * nflag + 4 + B,)   # hand-off state: (B, nflag) k_gate flags, [time-out, 3 spare], (B) ca flags, (B, nflag) BWD_FOLD flags
     ints = {"valid", "amax", "cidx", "sync"}
     out = {}
     for name, shp in shapes.items():

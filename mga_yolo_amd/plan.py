@@ -5,7 +5,7 @@ step are recorded once and replayed, instead of being issued from Python every s
 
 A ``PyramidPlan`` owns, per level: x, mask, y, gy, gx, gmask, ctx, scratch; and ONE flat fp32 bucket holding the parameter
 gradients of all levels (what data-parallel training all-reduces, see ``dp.py``).  ``forward`` / ``backward`` each make ONE
-library call on the current stream (6 kernel launches per step in total).  ``backward_params`` + ``backward_inputs`` is
+library call on the current stream (5 kernel launches per step in total).  ``backward_params`` + ``backward_inputs`` is
 the split form for callers that want the parameter gradients early (see ``dp.py``).
 """
 from __future__ import annotations
@@ -29,6 +29,8 @@ class PyramidPlan:
                  fuse_forward: Optional[bool] = None):
         # fuse_forward: k_chan + k_apply as ONE x-resident launch, k_gate (MGACBAM_FWD_FUSE); None = env MGACBAM_FUSE_FWD (on)
         self.fuse_forward = bool(int(os.environ.get("MGACBAM_FUSE_FWD", "1"))) if fuse_forward is None else bool(fuse_forward)
+        # transposed conv folded into the k_bwd_reduce1 launch (MGACBAM_BWD_FOLD) whenever the whole backward is one call
+        self.fold_backward = bool(int(os.environ.get("MGACBAM_FOLD_BWD", "1")))
         assert len(shapes) == len(params) == len(cfgs) and 1 <= len(shapes) <= _lib.MAX_LEVELS
         self.lib = _lib.load()
         self.device = torch.device(device)
@@ -86,7 +88,28 @@ class PyramidPlan:
         torch.cuda.synchronize(self.device)
         return all(int(self.ctx_view(l)["sync"].max()) > 0 for l in range(self.n))
 
+    def fold_active(self) -> bool:
+        """True when MGACBAM_BWD_FOLD really folds the transposed conv into the k_bwd_reduce1 launch for these shapes (the library
+        falls back to two launches for ineligible groups): the folded launch sets the backward hand-off flags, which stay set
+        until the k_bwd_apply of the same backward clears them."""
+        if not self.fold_backward:
+            return False
+        B = _lib.BWD_STAGES
+        self.forward()
+        self.backward(B["reduce1"] | B["convT"] | _lib.BWD_FOLD)
+        torch.cuda.synchronize(self.device)
+        hit = []
+        for l, (Bn, C, H, W) in enumerate(self.shapes):
+            sync = self.ctx_view(l)["sync"]
+            nf = Bn * ((H * W + 15) // 16 + 1)
+            hit.append(int(sync[nf + 4 + Bn:].max()) > 0)
+        self.backward((_lib.BWD_ALL & ~(B["reduce1"] | B["convT"])) | _lib.BWD_FOLD)      # finishes the step and clears the flags
+        torch.cuda.synchronize(self.device)
+        return all(hit)
+
     def backward(self, stages: int = _lib.BWD_ALL):
+        if stages == _lib.BWD_ALL and self.fold_backward:
+            stages |= _lib.BWD_FOLD     # ctx is zero-filled at allocation, as the flag's contract asks
         _lib.check(self.lib.mgacbam_backward_stages(self._bwd, self.n, stages, self._stream()), "mgacbam_backward_stages")
 
     def backward_params(self):

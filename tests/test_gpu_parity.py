@@ -370,7 +370,8 @@ def test_fused_forward_launch_equals_three_launches(F, shapes, with_mask, fused)
             sync = b["sync"]
             nf = B * ((H * W + 15) // 16 + 1)
             assert int(sync[nf:nf + 4].abs().sum()) == 0, (calls, l, "hand-off timed out")
-            assert bool((sync[nf + 4:] == (calls if fused else 0)).all()), (calls, l, "per-sample ca flags")
+            assert bool((sync[nf + 4:nf + 4 + B] == (calls if fused else 0)).all()), (calls, l, "per-sample ca flags")
+            assert int(sync[nf + 4 + B:].abs().sum()) == 0, (calls, l, "backward fold flags are 0 between calls")
             flags = sync[:nf]
             want = calls if fused else 0                                    # ineligible groups never touch the flags
             assert int(flags.max()) == want and set(flags.unique().tolist()) <= {0, want}, (calls, l)
@@ -443,7 +444,7 @@ def test_fused_forward_generation_flags_wrap_around(F):
         sync = plans[1].ctx_view(l)["sync"]
         nf = B * ((H * W + 15) // 16 + 1)
         sync[:nf] = 0x7FFFFFFE                      # every flag two calls before the wrap (as after 2^31 - 2 fused calls)
-        sync[nf + 4:] = 0x7FFFFFFE
+        sync[nf + 4:nf + 4 + B] = 0x7FFFFFFE
     for rep in range(4):
         for l in range(len(shapes)):
             plans[1].y[l].zero_()
