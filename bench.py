@@ -221,7 +221,7 @@ def main():
     def part_a():                # parameter-free prefix of the step: masked pooling
         plan.forward(S["pool"])
 
-    def part_b():                # everything that reads parameters: rest of forward, whole backward (6 launches/step in all)
+    def part_b():                # everything that reads parameters: rest of forward, whole backward (5 launches/step in all)
         plan.forward(S["chan"] | S["apply"])
         plan.backward()
 
