@@ -1,10 +1,12 @@
 // Backward kernels of the mask-guided CBAM block: the gradients autograd derives for
 // mga_yolo/nn/modules/masked_cbam.py:87-171, restated in SURVEY.md section 8a and oracle/maskcbam_oracle.py.
 //
-// With a = softplus(beta), u = x*ca, v = u*sa, N = H*W; four launches per step, each covering P3+P4+P5:
+// With a = softplus(beta), u = x*ca, v = u*sa, N = H*W; three launches per step (four without MGACBAM_BWD_FOLD), each covering
+// P3+P4+P5:
 //   k_bwd_reduce1  x, gy (1 read each) -> A[b,c] = sum_hw gy*x*sa, D[b,c] = sum_hw gy*(v-x)   (per hw-tile partials)
 //                                         g_pre[b,hw] = a * sa(1-sa) * sum_c ca*gy*x
-//   k_bwd_convT    g_pre               -> g_planes = conv_transpose(g_pre, Wsa)                    [tiny, critical path]
+//   k_bwd_convT    g_pre               -> g_planes = conv_transpose(g_pre, Wsa)     [tiny; with MGACBAM_BWD_FOLD its tiles are the
+//                                         last workgroups of the k_bwd_reduce1 launch and take g_pre over inside the launch]
 //   k_bwd_reduce2  x (1 read)          -> g_ca[b,c] = a*A + sum_hw x * ([c == cidx]*gp0 + gp1/C) ; g_z ; D ;
 //                                         per-channel-group partials of W2^T g_z
 //                                         + role workgroups (k_bwd_wsa body): dWsa tile partials

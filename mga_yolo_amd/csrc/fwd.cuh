@@ -1,14 +1,16 @@
 // Forward kernels of the mask-guided CBAM block (reference mga_yolo/nn/modules/masked_cbam.py:87-171).
 //
 //   k_pool   x (1 read)         -> avg, mx (+ arg-max), S/use/den, sigma(mask) plane                     [HBM-bound]
+//   k_gate   x (1 read, the tile stays in registers) -> role workgroups: shared MLP -> ca ; tiles: planes[max_c, mean_c], cidx,
+//                                  in-launch hand-off of the plane rows, k x k conv -> sa, y (1 write)      [MGACBAM_FWD_FUSE]
+//   fallback (shapes k_gate does not take, or without the flag):
 //   k_chan   x (1 read)         -> prologue: shared MLP -> ca ; body: planes[max_c, mean_c], cidx         [HBM-bound]
 //   k_apply  x (1 read), planes -> prologue: k x k conv of the tile -> sa ; body: y (1 write)             [HBM-bound]
 //
-// Three launches, each covering P3+P4+P5.  The two tiny steps of the block (the MLP: <= 74k MAC per sample; the
-// conv: 147 MAC per pixel on 3 planes) run as PROLOGUES of the streaming kernels instead of launches of their own:
-// a dependent tiny launch costs >= 5 us on MI355X (2.5 us boundary + a first load that always misses, because the
-// producer's lines sit in another XCD's L2) whatever its arithmetic, while a prologue costs one such miss,
-// overlapped with the workgroup's first feature loads.
+// Two (fallback: three) launches, each covering P3+P4+P5.  The two tiny steps of the block (the MLP: <= 74k MAC per sample;
+// the conv: 147 MAC per pixel on 3 planes) never get launches of their own: a dependent tiny launch costs >= 5 us on MI355X
+// (2.5 us boundary + a first load that always misses, because the producer's lines sit in another XCD's L2) whatever its
+// arithmetic, while a prologue / role workgroup costs one such miss, overlapped with the first feature loads.
 //
 // No kernel materialises cam_out / sam_out / the expanded mask (the reference makes ~15 full-size
 // temporaries).  Thread layout everywhere: 256 threads = TY rows x TX lanes, TX lanes run along H*W
