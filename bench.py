@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying hipGraphs")
+    ap.add_argument("--steps-per-graph", type=int, default=1,
+                    help="N = 1 only: steps recorded per hipGraph (diagnostic of the launch gap; the headline uses 1 = one replay per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the bounded CPU-baseline sample")
     ap.add_argument("--kernel-reps", type=int, default=30)
@@ -235,6 +237,8 @@ def main():
         g_all = plan.capture(whole)          # one graph per step: a graph boundary costs ~8 us on the device (rocprof trace)
         run_a = run_b = None
         run_all = g_all.replay
+        U = max(1, args.steps_per_graph)
+        g_multi = plan.capture(lambda: [whole() for _ in range(U)]) if U > 1 else None
     else:
         ga, gb = plan.capture(part_a), plan.capture(part_b)   # split only where the gradient exchange has to be joined
         run_a, run_b, run_all = ga.replay, gb.replay, None
@@ -258,8 +262,14 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if world == 1 and not args.no_graph and args.steps_per_graph > 1:     # diagnostic: exactly K steps, U per replay + the remainder
+        for _ in range(args.steps // U):
+            g_multi.replay()
+        for _ in range(args.steps % U):
+            step()
+    else:
+        for _ in range(args.steps):
+            step()
     exchange.finish()            # the last step's exchange is inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
@@ -313,7 +323,7 @@ def main():
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                     config=dict(workload=desc, batch_per_gpu=batch, global_batch=batch * world,
                                 levels=[list(s) for s in plan.shapes], parallelism=f"dp{world}", backend=(args.backend if world > 1 else None),
-                                launch="eager" if args.no_graph else ("hipGraph replay, 1 graph/step" if world == 1 else "hipGraph replay, 2 graphs/step (split at the gradient-exchange join)"),
+                                launch="eager" if args.no_graph else ((f"hipGraph replay, {max(1, args.steps_per_graph)} step(s)/graph" if args.steps_per_graph > 1 else "hipGraph replay, 1 graph/step") if world == 1 else "hipGraph replay, 2 graphs/step (split at the gradient-exchange join)"),
                                 grad_exchange=None if world == 1 else f"RCCL all-reduce of one {plan.grad_bucket.numel() * 4} B bucket per step, overlapped with the next step's parameter-free k_pool"),
                     roofline=roofline, step_roofline=step_roof, kernels=kernels, cpu_baseline=cpu,
                     lib=_lib.load().mgacbam_build_info().decode())
