@@ -1,6 +1,6 @@
 """Stage-wise comparison (forward statistics, then gradients) of specific shapes on the GPU box."""
 import os, sys, itertools
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from conftest import rel_err, synth

@@ -1,10 +1,10 @@
 """Randomised parity fuzz on the GPU box: many small random shapes / configurations of MaskCBAM and MaskECA through the HIP
 path vs the oracles (1e-4 relative).  Exercises every launch-geometry branch (H*W odd / multiple of 4, C below / above the row
 counts, B not a multiple of 8, generic conv sizes, no mask, raw-probability masks, tiny / empty masks, hidden 1..48).
-    python tools/fuzz_parity.py [n_cases] [seed]
+    python tests/fuzz/fuzz_parity.py [n_cases] [seed]
 """
 import os, random, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from conftest import rel_err, synth

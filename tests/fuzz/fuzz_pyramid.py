@@ -1,9 +1,9 @@
 """Randomised fuzz of the multi-level entry point: 2-5 levels per call with mixed shapes, conv sizes, mask / no mask, dtypes of
 their own -- exercises the launch-group partition (levels with different compile-time signatures go to different launches), the
 longest-first level ordering and the XCD-aligned grids.  Every level is checked against the oracle.
-    python tools/fuzz_pyramid.py [n_calls] [seed]"""
+    python tests/fuzz/fuzz_pyramid.py [n_calls] [seed]"""
 import os, random, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from conftest import rel_err, synth

@@ -1,8 +1,8 @@
 """Randomised parity fuzz of the smaller rows on the GPU box: segmentation loss (both modes, random level counts / sizes / target
 resolutions / weights / dtypes) vs its oracle, and the ProbMaskGater launch vs the module's host math on the same uniforms.
-    python tools/fuzz_rows.py [n_cases] [seed]"""
+    python tests/fuzz/fuzz_rows.py [n_cases] [seed]"""
 import os, random, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from oracle import segloss_oracle as SO
