@@ -545,7 +545,7 @@ def test_reentrant_from_two_threads_on_two_streams(F):
     (5, 3, 23, 17, 1, 1, "mixed"),
 ])
 def test_regressions_found_by_the_fuzzer(F, B, C, H, W, k, r, kind):
-    """Shapes that tools/fuzz_parity.py (randomised parity fuzz, 1000 cases on MI355X) once broke."""
+    """Shapes that tests/fuzz/fuzz_parity.py (randomised parity fuzz, 1000 cases on MI355X) once broke."""
     x, mask, gy = synth(B, C, H, W, seed=5, mask_kind=kind)
     p = O.Params.default_init(C, r=r, k=k, seed=1)
     cfg = O.Config(use_sigmoid_mask=kind != "prob")
