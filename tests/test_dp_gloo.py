@@ -33,7 +33,8 @@ def _worker(rank, world, port, B, C, H, W, q):
     overlapped = float(y.sum())                                 # independent work between start() and finish()
     ex.finish()
     ex.finish()                                                 # idempotent when nothing is pending
-    q.put((rank, bucket.clone(), g["gx"].clone(), sl.start, sl.stop, overlapped))
+    # plain arrays on the queue: torch tensors travel as shared-memory handles that die with the producer process
+    q.put((rank, bucket.numpy().copy(), g["gx"].numpy().copy(), sl.start, sl.stop, overlapped))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,6 +50,7 @@ def test_two_rank_gradient_exchange_matches_single_process():
     for p_ in procs:
         p_.start()
     got = [q.get(timeout=240) for _ in range(world)]
+    got = [(r, torch.from_numpy(b), torch.from_numpy(gx), lo, hi, ov) for r, b, gx, lo, hi, ov in got]
     for p_ in procs:
         p_.join(timeout=60)
         assert p_.exitcode == 0
@@ -61,6 +63,61 @@ def test_two_rank_gradient_exchange_matches_single_process():
         assert (bucket - want).abs().max() <= 1e-5 * want.abs().max(), rank      # same averaged bucket on every rank
         assert (gx - g["gx"][lo:hi]).abs().max() <= 1e-6 * g["gx"].abs().max()    # no collective in the data path
     assert torch.equal(got[0][1], got[1][1])
+
+
+def _ddp_worker(rank, world, port, B, C, H, W, q):
+    """The module inside the wrapper the reference's trainer uses: DistributedDataParallel(find_unused_parameters=True)
+    (U/engine/trainer.py:366-367), host path, with and without a mask (without one every parameter is still used)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from mga_yolo_amd import MaskCBAM
+    from mga_yolo_amd.dp import shard_batch
+    torch.manual_seed(0)
+    m = MaskCBAM(C)
+    ddp = DDP(m, find_unused_parameters=True)
+    x, mask, gy = synth(B, C, H, W, seed=43)
+    sl = shard_batch(B, world, rank)
+    out = {}
+    for tag, inp in (("mask", [x[sl], mask[sl]]), ("nomask", x[sl])):
+        ddp.zero_grad()
+        y = ddp(inp)
+        (y * gy[sl]).sum().backward()
+        out[tag] = {n: p.grad.numpy().copy() for n, p in m.named_parameters()}
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_module_inside_ddp_wrapper_averages_gradients():
+    from mga_yolo_amd import MaskCBAM
+    B, C, H, W, world = 4, 32, 10, 10, 2
+    ctx_mp = mp.get_context("spawn")
+    q = ctx_mp.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx_mp.Process(target=_ddp_worker, args=(r, world, port, B, C, H, W, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    got = dict(q.get(timeout=240) for _ in range(world))
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    torch.manual_seed(0)
+    m = MaskCBAM(C)
+    x, mask, gy = synth(B, C, H, W, seed=43)
+    for tag, inp in (("mask", [x, mask]), ("nomask", x)):
+        m.zero_grad()
+        (m(inp) * gy).sum().backward()
+        for n, p in m.named_parameters():
+            want = (p.grad / world).numpy()                          # DDP: mean over replicas of the per-shard sums
+            for r in range(world):
+                g = got[r][tag][n]
+                assert abs(g - want).max() <= 1e-5 * max(abs(want).max(), 1e-12), (tag, n, r)
+            assert (got[0][tag][n] == got[1][tag][n]).all()
 
 
 def test_shard_batch_is_an_equal_contiguous_partition():

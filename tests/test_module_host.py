@@ -99,27 +99,62 @@ def test_forward_hooks_see_a_plain_tensor():
     assert len(seen) == 1 and torch.equal(seen[0], y)
 
 
-def test_install_rebinds_the_reference_lookups():
-    """parse_model resolves 'MaskCBAM' through ultralytics.nn.tasks globals and tests identity against the same name."""
-    from mga_yolo_amd import MaskCBAM, install
-    fake = {}
-    for name in ("ultralytics", "ultralytics.nn", "ultralytics.nn.tasks", "mga_yolo", "mga_yolo.nn", "mga_yolo.nn.modules",
-                 "mga_yolo.nn.modules.masked_cbam", "mga_yolo.nn.losses", "mga_yolo.nn.losses.segmentation"):
-        fake[name] = types.ModuleType(name)
-    class Old:  # noqa: E306
-        pass
-    fake["ultralytics.nn.tasks"].MaskCBAM = Old
-    fake["ultralytics.nn"].MaskCBAM = Old
-    fake["mga_yolo.nn.modules.masked_cbam"].MaskCBAM = Old
+def _fake_reference(with_vendored_alias=True):
+    """Module names the reference really holds after `from mga_yolo.external.ultralytics.ultralytics import YOLO`: the vendored
+    tasks.py exists twice (top-level alias + full path), MGAModel derives from the DetectionModel of the full-path one."""
+    names = ["ultralytics", "ultralytics.nn", "ultralytics.nn.tasks", "mga_yolo", "mga_yolo.nn", "mga_yolo.nn.modules",
+             "mga_yolo.nn.modules.masked_cbam", "mga_yolo.nn.modules.masked_eca", "mga_yolo.nn.losses",
+             "mga_yolo.nn.losses.segmentation", "mga_yolo.model", "mga_yolo.model.model"]
+    if with_vendored_alias:
+        names += ["mga_yolo.external", "mga_yolo.external.ultralytics", "mga_yolo.external.ultralytics.ultralytics",
+                  "mga_yolo.external.ultralytics.ultralytics.nn", "mga_yolo.external.ultralytics.ultralytics.nn.tasks"]
+    fake = {n: types.ModuleType(n) for n in names}
+    RefCBAM, RefECA = type("MaskCBAM", (), {}), type("MaskECA", (), {})
+    fake["mga_yolo.nn.modules.masked_cbam"].MaskCBAM = RefCBAM
+    fake["mga_yolo.nn.modules.masked_eca"].MaskECA = RefECA
+    fake["mga_yolo.nn.losses.segmentation"].SegmentationLoss = type("SegmentationLoss", (), {})
+    fake["mga_yolo.nn.losses.segmentation"].SegLossConfig = type("SegLossConfig", (), {})
+    tasks = ["ultralytics.nn.tasks"] + (["mga_yolo.external.ultralytics.ultralytics.nn.tasks"] if with_vendored_alias else [])
+    for t in tasks:
+        fake[t].MaskCBAM, fake[t].MaskECA = RefCBAM, RefECA
+        fake[t.rsplit(".", 1)[0]].MaskCBAM = RefCBAM
+    factory = tasks[-1]
+    fake["mga_yolo.model.model"].DetectionModel = type("DetectionModel", (), {"__module__": factory})
+    return fake, factory, RefCBAM
+
+
+def _with_modules(fake, fn):
     saved = {k: sys.modules.get(k) for k in fake}
     sys.modules.update(fake)
     try:
+        return fn()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_install_rebinds_the_reference_lookups():
+    """parse_model resolves 'MaskCBAM' through the globals of ITS tasks module and tests identity against the same name; the
+    reference holds that module twice and MGAModel uses the `mga_yolo.external...` one -- install() runs AFTER the reference was
+    imported and must reach both."""
+    from mga_yolo_amd import MaskCBAM, MaskECA, install
+    fake, factory, RefCBAM = _fake_reference()
+    assert factory == "mga_yolo.external.ultralytics.ultralytics.nn.tasks"
+
+    def body():
         patched = install(strict=True)
-        assert "ultralytics.nn.tasks" in patched and "mga_yolo.nn.modules.masked_cbam" in patched
-        tasks = sys.modules["ultralytics.nn.tasks"]
-        assert tasks.MaskCBAM is MaskCBAM and vars(tasks)["MaskCBAM"] is MaskCBAM      # globals()[m] and `m is MaskCBAM`
-        built = vars(tasks)["MaskCBAM"](64)                                            # parse_model: MaskCBAM(c_in)
-        assert isinstance(built, sys.modules["mga_yolo.nn.modules.masked_cbam"].MaskCBAM)   # trainer's alpha logger
+        for t in ("ultralytics.nn.tasks", factory, "mga_yolo.nn.modules.masked_cbam", "mga_yolo.nn.modules.masked_eca",
+                  "ultralytics.nn", "mga_yolo.external.ultralytics.ultralytics.nn", "mga_yolo.nn.losses.segmentation"):
+            assert t in patched, (t, patched)
+        for t in ("ultralytics.nn.tasks", factory):
+            tasks = sys.modules[t]
+            assert vars(tasks)["MaskCBAM"] is MaskCBAM and vars(tasks)["MaskECA"] is MaskECA      # globals()[m] and `m is MaskCBAM`
+        built = vars(sys.modules[factory])["MaskCBAM"](64)                                     # parse_model: MaskCBAM(c_in)
+        assert isinstance(built, sys.modules["mga_yolo.nn.modules.masked_cbam"].MaskCBAM)      # trainer's alpha logger
+        assert not isinstance(built, RefCBAM)
         # MGAModel.init_criterion: `from mga_yolo.nn.losses.segmentation import SegmentationLoss, SegLossConfig` at call time
         from mga_yolo_amd import SegLossConfig, SegmentationLoss
         losses = sys.modules["mga_yolo.nn.losses.segmentation"]
@@ -128,12 +163,30 @@ def test_install_rebinds_the_reference_lookups():
                                                             loss_lambda=1.0, enabled=True))       # model.py:105-117
         total, logs = crit({"p3": torch.zeros(1, 1, 4, 4)}, [torch.zeros(1, 1, 4, 4)])
         assert total.shape == () and "seg_total" in logs
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                sys.modules.pop(k, None)
-            else:
-                sys.modules[k] = v
+        assert install(strict=True) == patched                                                    # idempotent
+    _with_modules(fake, body)
+
+
+def test_install_strict_requires_the_factory_namespace():
+    """strict=True: the module providing mga_yolo.model.model.DetectionModel must have been patched -- patching only the
+    top-level alias would leave MGAModel building the reference classes (the round-1 bug)."""
+    from mga_yolo_amd import MaskCBAM, install
+    fake, factory, _ = _fake_reference()
+    del fake[factory].MaskCBAM, fake[factory].MaskECA          # nothing to rebind in the namespace parse_model reads
+
+    def body():
+        with pytest.raises(RuntimeError, match="could not be patched"):
+            install(strict=True)
+        assert "ultralytics.nn.tasks" in install(strict=False)
+    _with_modules(fake, body)
+    # guarded import left `MaskCBAM = None` in tasks.py (U/nn/tasks.py:87-90): install fills it in
+    fake, factory, _ = _fake_reference()
+    fake[factory].MaskCBAM = None
+
+    def body2():
+        install(strict=True)
+        assert sys.modules[factory].MaskCBAM is MaskCBAM
+    _with_modules(fake, body2)
 
 
 def test_prob_mask_gater_semantics():
