@@ -65,7 +65,8 @@ def parse():
     ap.add_argument("--steps-per-graph", type=int, default=1,
                     help="N = 1 only: steps recorded per hipGraph (diagnostic of the launch gap; the headline uses 1 = one replay per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the bounded CPU-baseline sample")
+    ap.add_argument("--no-eager", action="store_true", help="skip the eager-module (unchanged-trainer) timing")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the bounded CPU-baseline sample (>= 50 iterations at config 2 need ~15 s)")
     ap.add_argument("--kernel-reps", type=int, default=30)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "bf16"], help="element type of x / y / gy / gx (headline = f32)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for rehearsing the multi-rank code path on one GPU)")
@@ -143,24 +144,84 @@ def time_kernels(plan, reps):
     o1.record()
     torch.cuda.synchronize()
     t_outer = o0.elapsed_time(o1) * 1e3 / reps
-    out = {}
+    out, fast = {}, {}
     keep = max(1, (3 * reps) // 4)
     for k, (name, _, _) in enumerate(seq):
         ts = sorted(ev[r][k].elapsed_time(ev[r][k + 1]) * 1e3 for r in range(reps))
-        out[name] = sum(ts[:keep]) / keep                       # mean of the fastest 75 % (drops host hiccups)
-    pad = max(0.0, (sum(out.values()) - t_outer) / len(seq))     # (t_outer has the same number of launches)
-    out = {k: max(v - pad, 0.0) for k, v in out.items()}
+        out[name] = sum(ts) / len(ts)                           # plain mean over all repetitions (what roofline.achieved uses)
+        fast[name] = sum(ts[:keep]) / keep                      # mean of the fastest 75 % (extra key: drops host hiccups)
+    pad = max(0.0, (sum(out.values()) - t_outer) / len(seq))     # what the inner event records cost on the stream (reported, NOT subtracted)
     out["_event_pad_us"] = pad
     out["_folded"] = folded
+    out["_fast75"] = fast
     return out
 
 
+def eager_module_step(workload, device, dtype_name, steps=60, warmup=10):
+    """The path the reference's UNCHANGED layer loop takes (mga_yolo/model/model.py:57-64): three `MaskCBAM` modules called one
+    after the other through autograd (one library call forward and one backward PER LEVEL, every launch issued from Python),
+    no PyramidPlan, no hipGraph.  Returns ms per forward+backward step over the three levels."""
+    import torch
+    from mga_yolo_amd import MaskCBAM
+    desc, batch, lv = WORKLOADS[workload]
+    dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dtype_name]
+    g = torch.Generator().manual_seed(99)
+    mods, data = [], []
+    for (C, H, W) in lv:
+        torch.manual_seed(0)
+        mods.append(MaskCBAM(C).to(device))
+        x = torch.nn.functional.silu(torch.randn(batch, C, H, W, generator=g)).to(device, dt).requires_grad_(True)
+        m = (torch.randn(batch, 1, H, W, generator=g) - 2.0).to(device).requires_grad_(True)
+        gy = torch.randn(batch, C, H, W, generator=g).to(device, dt)
+        data.append((x, m, gy))
+
+    def step():
+        ys = [mod([x, m]) for mod, (x, m, _) in zip(mods, data)]
+        torch.autograd.backward(ys, [gy for _, _, gy in data])
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / steps
+
+
+def host_cpu_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = logical
+    quota = None
+    try:                                                          # cgroup v2 CPU quota of this container, if any
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    usable = min(x for x in (logical, affinity, quota) if x)
+    return dict(model=model, logical_cpus=logical, affinity=affinity, cgroup_quota=quota, usable=usable)
+
+
 def cpu_baseline(workload, seconds):
-    """The oracle's eager-op form = the reference's PyTorch-CPU op sequence, fwd+bwd over the three levels."""
+    """The oracle's eager-op form = the reference's PyTorch-CPU op sequence, fwd+bwd over the three levels, timed on this box's
+    host cores (BASELINE.md section 3 protocol: all usable cores, warm-up, >= 50 timed iterations unless the time budget runs
+    out, median + p10 / p90)."""
     import torch
     from oracle import maskcbam_oracle as O
     desc, batch, lv = WORKLOADS[workload]
-    cores = min(16, os.cpu_count() or 1)                         # the box's CPU share for one GPU
+    info = host_cpu_info()
+    cores = info["usable"]
     torch.set_num_threads(cores)
     sample_batch = batch
     g = torch.Generator().manual_seed(1234)
@@ -175,18 +236,24 @@ def cpu_baseline(workload, seconds):
     def one():
         for x, mask, gy, p in data:
             O.reference_form_step(x, mask, p, cfg, gy)
-    one()                                                        # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while True:
+    for _ in range(3):                                           # warm-up
         one()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > seconds or n >= 50:
-            break
-    return dict(value=round(sample_batch * n / el, 2), unit="images/s", cores=cores, kind="port",
-                sample=f"{n} fwd+bwd steps of the oracle's eager-op form (oracle/maskcbam_oracle.py:reference_form_step) "
-                       f"over P3+P4+P5 at batch {sample_batch}, torch CPU fp32, {cores} threads, {el:.1f} s")
+    ts = []
+    t_start = time.perf_counter()
+    while len(ts) < 50 and (time.perf_counter() - t_start) < seconds:
+        t0 = time.perf_counter()
+        one()
+        ts.append(time.perf_counter() - t0)
+    el = sum(ts)
+    srt = sorted(ts)
+    pct = lambda q: srt[min(len(srt) - 1, int(q * len(srt)))]
+    med = pct(0.5)
+    return dict(value=round(sample_batch / med, 2), unit="images/s", cores=cores, kind="port",
+                cpu_model=info["model"], logical_cpus=info["logical_cpus"], affinity=info["affinity"], cgroup_quota=info["cgroup_quota"],
+                iterations=len(ts), ms_median=round(med * 1e3, 2), ms_p10=round(pct(0.1) * 1e3, 2), ms_p90=round(pct(0.9) * 1e3, 2),
+                images_per_s_mean=round(sample_batch * len(ts) / el, 2),
+                sample=f"{len(ts)} fwd+bwd steps (median) of the oracle's eager-op form (oracle/maskcbam_oracle.py:reference_form_step) "
+                       f"over P3+P4+P5 at batch {sample_batch}, torch CPU fp32, {cores} threads on {info['model']}, {el:.1f} s")
 
 
 def main():
@@ -215,6 +282,11 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    if world > ndev:
+        # rehearsal only (several ranks on ONE card): the CUs are shared, so the co-residency the in-launch hand-offs are sized for
+        # does not hold -- run the three-launch forward / unfolded backward (what `MGACBAM_FUSE_FWD=0` selects)
+        os.environ["MGACBAM_FUSE_FWD"] = "0"
+        os.environ["MGACBAM_FOLD_BWD"] = "0"
     plan, desc, batch = make_plan(args.workload, device, seed=1234 + rank, dtype_name=args.dtype)
     exchange = GradExchange(plan.grad_bucket)                    # no-op when world == 1
 
@@ -258,9 +330,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import gc
     for _ in range(args.warmup):
         step()
     fence()
+    gc.collect()
+    gc.disable()                 # a collector pause inside a 4-40 ms timed region is host noise, not the path being measured
     t0 = time.perf_counter()
     if world == 1 and not args.no_graph and args.steps_per_graph > 1:     # diagnostic: exactly K steps, U per replay + the remainder
         for _ in range(args.steps // U):
@@ -273,6 +348,8 @@ def main():
     exchange.finish()            # the last step's exchange is inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    plan.check_handoff()         # raises if any in-launch hand-off of the run timed out (the step would have been wrong AND slow)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -287,32 +364,43 @@ def main():
     w = 4 if args.dtype == "f32" else 2
     kernels = {}
     event_pad = kt.pop("_event_pad_us")
+    fast75 = kt.pop("_fast75")
     symbols = dict(KERNEL_SYMBOL, **(KERNEL_SYMBOL_FOLD if kt.pop("_folded") else {}))
     for name, us in kt.items():
         side, k = name.split(".")
         mult = (FWD_KERNEL_E if side == "fwd" else BWD_KERNEL_E).get(k)
-        ent = dict(us=round(us, 2), launches=1, symbol=symbols[name])
+        ent = dict(us=round(us, 2), us_fastest75=round(fast75[name], 2), launches=1, symbol=symbols[name])
         if mult:
             ent["alg_bytes"] = mult * E * w
             ent["GBps"] = round(mult * E * w / us / 1e3, 1)
         kernels[name] = ent
     dom = max((n for n in kernels if "alg_bytes" in kernels[n]), key=lambda n: kernels[n]["us"])
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")   # PMC-derived HBM bytes (collected with rocprofv3, see profiles/)
+    # roofline.traffic = HBM bytes per launch from the PMC counters: they need rocprofv3 passes of their own (FETCH_SIZE / WRITE_SIZE,
+    # MI355X_MICROARCH.md), so the figure is NOT measured in this run -- it is read from the committed summary of the last
+    # profiling run and tagged with where it came from
+    traffic, traffic_source = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.workload, {}).get(symbols[dom])
+            tj = json.load(open(tpath))
+            traffic = tj.get(args.workload if args.dtype == "f32" else f"{args.workload}_{args.dtype}", {}).get(symbols[dom])
+            traffic_source = tj.get("_source")
         except Exception:
             traffic = None
     roofline = dict(bound="hbm", kernel=symbols[dom], stage=dom, achieved=kernels[dom]["GBps"], peak=HBM_PEAK_GBPS, unit="GB/s",
-                    frac=round(kernels[dom]["GBps"] / HBM_PEAK_GBPS, 4), traffic=traffic,
+                    frac=round(kernels[dom]["GBps"] / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_source,
                     alg_bytes_per_launch=kernels[dom]["alg_bytes"], us=kernels[dom]["us"],
-                    note="one launch covers P3+P4+P5; duration = mean elapsed time between an event recorded before and one after the launch, on the launch stream, with the step issued in order")
+                    note="one launch covers P3+P4+P5; duration = plain mean over the repetitions of the elapsed time between an event recorded before and one after the launch, on the launch stream, with the step issued in order")
     step_alg = 8 * E * w                                           # forward 3*E*w + backward 5*E*w
     step_roof = dict(alg_bytes=step_alg, GBps=round(step_alg / (ms_per_step * 1e-3) / 1e9, 1),
                      frac=round(step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                      sum_kernel_us=round(sum(kt.values()), 1), event_pad_us=round(event_pad, 2))
 
+    eager_ms = None
+    if rank == 0 and world == 1 and not args.no_eager:
+        eager_ms = round(eager_module_step(args.workload, device, args.dtype), 4)
+        from mga_yolo_amd import handoff_report
+        handoff_report()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, args.cpu_seconds)
@@ -324,8 +412,11 @@ def main():
                     config=dict(workload=desc, batch_per_gpu=batch, global_batch=batch * world,
                                 levels=[list(s) for s in plan.shapes], parallelism=f"dp{world}", backend=(args.backend if world > 1 else None),
                                 launch="eager" if args.no_graph else ((f"hipGraph replay, {max(1, args.steps_per_graph)} step(s)/graph" if args.steps_per_graph > 1 else "hipGraph replay, 1 graph/step") if world == 1 else "hipGraph replay, 2 graphs/step (split at the gradient-exchange join)"),
-                                grad_exchange=None if world == 1 else f"RCCL all-reduce of one {plan.grad_bucket.numel() * 4} B bucket per step, overlapped with the next step's parameter-free k_pool"),
+                                grad_exchange=None if world == 1 else f"{'RCCL' if args.backend == 'nccl' else args.backend} all-reduce of one {plan.grad_bucket.numel() * 4} B bucket per step, overlapped with the next step's parameter-free k_pool",
+                                handoff_kernels=bool(plan.fuse_forward)),
                     roofline=roofline, step_roofline=step_roof, kernels=kernels, cpu_baseline=cpu,
+                    eager_module_ms_per_step=eager_ms,
+                    eager_module_note="the unchanged reference layer loop's path: three MaskCBAM modules through autograd, one library call per level each way, launches issued from Python (no PyramidPlan / hipGraph)",
                     lib=_lib.load().mgacbam_build_info().decode())
         print(json.dumps(line))
     if world > 1:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MGACBAM_ABI_VERSION 8
+#define MGACBAM_ABI_VERSION 9
 #define MGACBAM_MAX_LEVELS 8          /* P3/P4/P5 need 3 */
 
 enum { MGACBAM_F32 = 0, MGACBAM_F16 = 1, MGACBAM_BF16 = 2 };
@@ -121,11 +121,18 @@ typedef struct mgacbam_ctx_layout {
   int64_t cidx;     /* (B,HW)   int32: first arg-max channel of u          masked_cbam.py:135 */
   int64_t sa;       /* (B,HW)   spatial gate                              masked_cbam.py:147 */
   int64_t proj;     /* (B,hid,HW) W1-projection of x, only when hid <= MGACBAM_PROJ_MAX_HIDDEN (else empty)  */
-  int64_t sync;     /* int32: (B, ceil(HW/16)+1) tile generation flags of MGACBAM_FWD_FUSE (see there), 4 status words, (B) ca flags, (B, ceil(HW/16)+1) MGACBAM_BWD_FOLD tile flags */
+  int64_t sync;     /* int32 hand-off state, generation counters that are never reset: (B, ceil(HW/16)+1) tile flags of MGACBAM_FWD_FUSE
+                       (see there), 4 status words, (B) ca flags, 2 x (B, ceil(HW/16)+1) MGACBAM_BWD_FOLD tile / conv-tile flags */
   int64_t total;    /* == mgacbam_ctx_bytes()                                                 */
+  int64_t status;   /* int32 status word inside `sync`: 0 = every in-launch hand-off of every call on this ctx completed; non-zero =
+                       one timed out (that tile's outputs were poisoned with NaN).  The caller reads these 4 bytes wherever it
+                       synchronises anyway (mga_yolo_amd: PyramidPlan.check_handoff(), and per call with MGACBAM_CHECK_HANDOFF=1) */
 } mgacbam_ctx_layout_t;
 
 int mgacbam_abi_version(void);
+/* Tuning / test knobs (MGACBAM_* environment variables) are read once, at the first call; this re-reads them.  Not to be called
+ * concurrently with other entry points. */
+void mgacbam_reload_env(void);
 const char* mgacbam_last_error(void);      /* thread-local, valid until the next call on this thread */
 const char* mgacbam_build_info(void);      /* "gfx950 hipcc-x.y ..." */
 
@@ -153,11 +160,14 @@ enum {
                                 tiles through generation flags; one role workgroup per sample runs the shared MLP.
                                 CONTRACT: the caller zero-fills ctx[sync .. total) once after allocating ctx (and again
                                 after a call that was aborted mid-flight); the library keeps that state consistent.
-                                Levels whose shape is not eligible (C > 4096, tiles under 16 px, very wide k x k halos)
-                                run as three launches as without the flag.  Waits are bounded: a hand-off that times
-                                out (never expected -- a consumer only waits for workgroups a few ids away, dispatched
-                                before or with it) sets status word 0 (int32 at ctx[sync + 4*B*(ceil(HW/16)+1)]) and the
-                                launch still drains; tests assert it stays 0                                           */
+                                Eligibility is decided per launch group from the shape (C <= 4096, tiles >= 16 px and >= one
+                                image row, halo rows fit in LDS) AND from the device: a tile waits for tiles up to 8*span
+                                workgroup ids ahead, so 2*(8*span+1) workgroups of the chosen kernel must be co-resident
+                                (multiProcessorCount x occupancy; MGACBAM_RESIDENT_WGS overrides) -- otherwise the group
+                                runs as three launches as without the flag.  Waits are bounded: a hand-off that times out
+                                (the device is shared with other work that takes the CUs away) sets the status word
+                                (mgacbam_ctx_layout_t.status), POISONS that tile's sa / y with NaN and the launch still drains:
+                                a failure is loud in the loss, never a silently stale halo                              */
 };
 enum {
   MGACBAM_BWD_REDUCE1 = 1,    /* k_bwd_reduce1: sums of gy*x over H*W and over C                reads x, gy       */
@@ -174,11 +184,12 @@ enum {
   MGACBAM_BWD_INPUTS = 32,    /* the stage only the input gradients depend on                   */
   MGACBAM_BWD_ALL = 127,
   MGACBAM_BWD_FOLD = 128      /* with REDUCE1 + CONVT: the transposed-conv tiles run as the LAST workgroups of the REDUCE1 launch and
-                                 pick the g_pre rows up inside the launch (one flag per REDUCE1 tile in ctx.sync; contract as
-                                 MGACBAM_FWD_FUSE: the caller zero-filled ctx[sync .. total) once).  With APPLY: that launch
-                                 clears the flags again -- a folded REDUCE1 must be followed by an APPLY carrying this bit
-                                 before the next one on the same ctx (mgacbam_backward_stages(MGACBAM_BWD_ALL | MGACBAM_BWD_FOLD)
-                                 does both).  Not part of MGACBAM_BWD_ALL: mgacbam_backward() works on an un-zeroed ctx      */
+                                 pick the g_pre rows up inside the launch (one generation counter per REDUCE1 tile and per conv
+                                 tile in ctx.sync; contract as MGACBAM_FWD_FUSE: the caller zero-filled ctx[sync .. total) once).
+                                 The counters are never reset, so a backward that stops after this launch leaves a consistent
+                                 state.  The conv tiles wait only for lower-numbered workgroups that never wait themselves, so
+                                 progress does not depend on residency; a time-out still poisons (NaN g_planes -> gx) and sets
+                                 the status word.  Not part of MGACBAM_BWD_ALL: mgacbam_backward() works on an un-zeroed ctx  */
 };
 int mgacbam_forward_stages(const mgacbam_fwd_level_t* levels, int n_levels, int stages, void* stream);
 int mgacbam_backward_stages(const mgacbam_bwd_level_t* levels, int n_levels, int stages, void* stream);
@@ -236,8 +247,8 @@ int mgacbam_eca_backward(const mgacbam_eca_bwd_level_t* levels, int n_levels, vo
 /* ------------------------------------------------------------------------------------------------
  * Multi-scale segmentation loss on the mask logits: replaces SegmentationLoss.forward in its default mode,
  * mga_yolo/nn/losses/segmentation.py:87-151 (BCEWithLogits(mean) + soft Dice per level, scale weights, loss_lambda) and its
- * autograd backward.  Targets at another resolution are gathered with F.interpolate(mode="nearest")'s index rule
- * (segmentation.py:103-110).  use_unified_focal selects the Unified Focal mode (_lmf :44-63, _lmft :65-85, combine :114-131).
+ * autograd backward.  Targets at another resolution are gathered inside the kernels: F.interpolate(mode="nearest")'s index rule
+ * (segmentation.py:110) or the 4-tap bilinear rule with align_corners=False (segmentation.py:103-108).  use_unified_focal selects the Unified Focal mode (_lmf :44-63, _lmft :65-85, combine :114-131).
  * ------------------------------------------------------------------------------------------------ */
 #define MGASEG_MAX_LEVELS 4
 typedef struct mgaseg_level {
@@ -247,7 +258,10 @@ typedef struct mgaseg_level {
   int32_t B, H, W, Ht, Wt;
   int32_t dtype;             /* MGACBAM_F32 / F16 / BF16                                        */
   float scale_weight;        /* SegLossConfig.scale_weights[i]                                  */
+  int32_t resize;            /* target at another resolution: MGASEG_NEAREST (segmentation.py:110) or MGASEG_BILINEAR
+                                (align_corners=False; the MGA_PROB_MODE branch, segmentation.py:103-108)                      */
 } mgaseg_level_t;
+enum { MGASEG_NEAREST = 0, MGASEG_BILINEAR = 1 };
 typedef struct mgaseg_cfg {                                   /* SegLossConfig, segmentation.py:9-21 */
   float bce_weight, dice_weight, smooth, loss_lambda;
   int32_t use_unified_focal;
@@ -259,6 +273,14 @@ size_t mgaseg_ws_bytes(const mgaseg_level_t* levels, int n_levels);   /* workspa
 int mgaseg_forward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, void* ws, float* out, void* stream);
 /* gout: device scalar dL/d(total) */
 int mgaseg_backward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, const void* ws, const float* gout, void* stream);
+
+/* Kendall multi-task combine of MGAModel.loss (mga_yolo/model/model.py:204-206), on the device so that no loss value has to visit
+ * the host:  total[i] = exp(-s_det) * det[i] + s_det + exp(-s_seg) * seg + s_seg   for the n_det entries of the detection-loss vector
+ * (box, cls, dfl); log_vars = {s_det, s_seg} (the learnable mtl_log_vars).  Backward: g_det[i], g_seg, g_log_vars[2] from g_total[i].
+ * All fp32 device pointers; one tiny launch each. */
+int mgakendall_forward(const float* det, int n_det, const float* seg, const float* log_vars, float* total, void* stream);
+int mgakendall_backward(const float* det, int n_det, const float* seg, const float* log_vars, const float* g_total,
+                        float* g_det, float* g_seg, float* g_log_vars, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * ProbMaskGater: mga_yolo/nn/modules/probmaskgater.py:58-98, training mode, 'gumbel' (hard = 0) and 'hard_st'

@@ -8,7 +8,7 @@ import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGACBAM_LIB") or os.path.join(_PKG, "libmgacbam.so")   # MGACBAM_LIB: A/B builds in tuning sweeps
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_LEVELS = 8
 F32, F16, BF16 = 0, 1, 2
 # stage bit masks (include/mgacbam.h)
@@ -61,7 +61,7 @@ class EcaBwdLevel(C.Structure):                  # mgacbam_eca_bwd_level_t
                 ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dtype", C.c_int32)]
 
 
-CTX_FIELDS = ("S", "use", "den", "avg", "mx", "mavg", "valid", "amax", "h_avg", "h_mx", "ca", "planes", "cidx", "sa", "proj", "sync", "total")
+CTX_FIELDS = ("S", "use", "den", "avg", "mx", "mavg", "valid", "amax", "h_avg", "h_mx", "ca", "planes", "cidx", "sa", "proj", "sync", "total", "status")
 
 
 class CtxLayout(C.Structure):                    # mgacbam_ctx_layout_t
@@ -72,7 +72,7 @@ class CtxLayout(C.Structure):                    # mgacbam_ctx_layout_t
 class SegLevel(C.Structure):                     # mgaseg_level_t
     _fields_ = [("logits", C.c_void_p), ("target", C.c_void_p), ("glogits", C.c_void_p),
                 ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ht", C.c_int32), ("Wt", C.c_int32),
-                ("dtype", C.c_int32), ("scale_weight", C.c_float)]
+                ("dtype", C.c_int32), ("scale_weight", C.c_float), ("resize", C.c_int32)]
 
 
 class SegCfg(C.Structure):                       # mgaseg_cfg_t
@@ -81,6 +81,7 @@ class SegCfg(C.Structure):                       # mgaseg_cfg_t
 
 
 SEG_MAX_LEVELS = 4
+SEG_NEAREST, SEG_BILINEAR = 0, 1
 
 
 class PmgCfg(C.Structure):                       # mgapmg_cfg_t
@@ -91,6 +92,7 @@ SYMBOLS = {
     "mgacbam_abi_version": (C.c_int, []),
     "mgacbam_last_error": (C.c_char_p, []),
     "mgacbam_build_info": (C.c_char_p, []),
+    "mgacbam_reload_env": (None, []),
     "mgacbam_ctx_bytes": (C.c_size_t, [C.c_int] * 5),
     "mgacbam_bwd_scratch_bytes": (C.c_size_t, [C.c_int] * 6),
     "mgacbam_ctx_layout": (C.c_int, [C.c_int] * 5 + [C.POINTER(CtxLayout)]),
@@ -106,6 +108,8 @@ SYMBOLS = {
     "mgaseg_ws_bytes": (C.c_size_t, [C.POINTER(SegLevel), C.c_int]),
     "mgaseg_forward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgaseg_backward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgakendall_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgakendall_backward": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 7),
     "mgapmg_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_size_t, C.POINTER(PmgCfg), C.c_void_p]),
     "mgapmg_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_size_t, C.POINTER(PmgCfg), C.c_void_p]),
 }
@@ -143,6 +147,11 @@ def load():
             raise LibraryMissing(f"{LIB_PATH} has ABI version {v}, expected {ABI_VERSION}; rebuild it")
         _lib = lib
         return lib
+
+
+def reload_env():
+    """Make the library re-read its MGACBAM_* knobs (they are read once; tests and tuning sweeps change them in-process)."""
+    load().mgacbam_reload_env()
 
 
 def available() -> bool:

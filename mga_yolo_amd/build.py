@@ -15,8 +15,13 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmgacbam.so")
 SOURCES = ["mgacbam_api.hip"]
-HEADERS = ["args.cuh", "common.cuh", "fwd.cuh", "bwd.cuh", os.path.join(ROOT, "include", "mgacbam.h")]
 ARCH = "gfx950"
+
+
+def dependencies():
+    """Everything the library is compiled from: every file under csrc/ (all .cuh are included by mgacbam_api.hip) + the public header."""
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cuh", ".h"))]
+    return deps + [os.path.join(ROOT, "include", "mgacbam.h")]
 
 
 def hipcc_path() -> str:
@@ -30,8 +35,7 @@ def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in dependencies())
 
 
 def build(force: bool = False, verbose: bool = False, resource_log: str | None = None, defines=(), out: str | None = None) -> str:

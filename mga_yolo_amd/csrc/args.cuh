@@ -24,7 +24,8 @@ struct CtxPtrs {
   float* h_avg; float* h_mx; float* ca;
   float* planes; int* cidx; float* sa;
   float* proj;     // (B, hidden, HW) when hidden <= kProjMax
-  int* sync;       // in-launch hand-off state: [B][nflag] tile generation flags, 4 status words ([0] = time-out), [B] per-sample ca generation flags, [B][nflag] k_bwd_reduce1 tile flags (MGACBAM_BWD_FOLD; 0 between calls)
+  int* sync;       // in-launch hand-off state, all generation counters (zero-filled once by the caller, never reset): [B][nflag] k_gate tile flags,
+                   // 4 status words ([0] = time-out), [B] per-sample ca flags, [B][nflag] k_bwd_reduce1 tile flags, [B][nflag] folded conv-tile flags
 };
 
 struct ParamPtrs { const float* w1; const float* b1; const float* w2; const float* b2; const float* wsa; const float* beta; };
@@ -41,6 +42,7 @@ struct Tune {
   int nt_stores;   // 1: y / gx are written with non-temporal stores
   int gate_rows;   // k_gate: upper bound of the plane rows (tile rows + halo) staged per workgroup
   int gate_tx;     // k_gate (x-resident chan+apply): TX lanes along H*W, TY = 256/TX slices of kGateR channels each; 0 = not eligible
+  int gate_span;   // k_gate: tiles a k x k window reaches on either side (a tile waits for workgroups up to 8*span ids away)
 };
 
 struct FwdArgs {
@@ -48,6 +50,8 @@ struct FwdArgs {
   CtxPtrs c; ParamPtrs p; Geo g; Tune t;
   int nflag;       // flags per sample in c.sync (host: sync_flags(HW))
   int fused;       // MGACBAM_FWD_FUSE path selected for this level's group
+  unsigned spin_limit;   // bound of every hand-off spin (knob MGACBAM_SPIN_LIMIT, default 2^20 ~ 1 s)
+  int fault;       // fault injection for tests (knob MGACBAM_FAULT=1): sample 0's role workgroup never publishes ca
   long long* trace;   // MGACBAM_TRACE builds only: per-workgroup phase timestamps (tools/trace_gate.py), else nullptr
 };
 
@@ -75,8 +79,9 @@ struct BwdArgs {
   int ncg;      // channel groups per sample of k_bwd_reduce2
   int nflag;    // flags per sample in c.sync
   int bflag0;   // first backward hand-off flag in c.sync (ints): [B][nflag], one per k_bwd_reduce1 tile
+  int cflag0;   // first flag of the folded transposed-conv tiles in c.sync: [nconv], generation counters like the tile flags
+  unsigned spin_limit;
   int vec;      // elements per lane of the tile kernels (TP = chan_tx * vec pixels per tile)
-  int fold;     // MGACBAM_BWD_FOLD active for this call: k_bwd_apply clears the flags again
   long long* trace;   // MGACBAM_TRACE builds only (tools/trace_gate.py), else nullptr
 };
 

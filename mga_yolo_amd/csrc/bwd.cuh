@@ -143,11 +143,17 @@ __device__ __forceinline__ void bwd_convT_body(const BwdArgs& A, const int local
   float* tg = smem + ((3 * k * k + 3) & ~3);   // g_pre tile + halo
   for (int i = tid; i < 3 * k * k; i += kBlock) wts[i] = A.p.wsa[i];
   const float* gpre = A.s.gpre + static_cast<size_t>(c.b) * g.HW;
+  bool bad = false;
   if (COH) {
+    // generation counters: every k_bwd_reduce1 tile and every folded conv tile bumps its own flag exactly once per folded launch, so
+    // after n such launches every flag reads n -- nothing is reset, and a backward that stops half-way leaves a consistent state
+    int* own = A.c.sync + A.cflag0 + local;
+    const int gen = static_cast<int>(static_cast<unsigned>(ld_agent(own)) + 1u);
     const int TP = A.t.chan_tx * A.vec;                        // pixels per k_bwd_reduce1 tile
     const int ra = max(c.y0 - c.pad, 0), rb = min(c.y0 + c.TH - 1 + c.pad, g.H - 1);
-    handoff_wait(A.c.sync + A.bflag0 + static_cast<size_t>(c.b) * A.nflag, (ra * g.W) / TP, ((rb + 1) * g.W - 1) / TP, 1,
-                 A.c.sync + static_cast<size_t>(g.B) * A.nflag);
+    bad = handoff_wait(A.c.sync + A.bflag0 + static_cast<size_t>(c.b) * A.nflag, (ra * g.W) / TP, ((rb + 1) * g.W - 1) / TP, gen,
+                       A.c.sync + static_cast<size_t>(g.B) * A.nflag, A.spin_limit);
+    if (tid == 0) __hip_atomic_fetch_add(own, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   stage_window<8>(tg, 1, c.PH, c.PW, c.y0 - c.pad, c.x0 - c.pad, g, [&](int, int off) { return COH ? ld_agent(gpre + off) : gpre[off]; });
   __syncthreads();
@@ -199,7 +205,7 @@ __device__ __forceinline__ void bwd_convT_body(const BwdArgs& A, const int local
       if (xg < g.W) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          A.s.gplanes[(static_cast<size_t>(c.b) * 3 + p) * g.HW + yg * g.W + xg] = acc[p][e];
+          A.s.gplanes[(static_cast<size_t>(c.b) * 3 + p) * g.HW + yg * g.W + xg] = bad ? __builtin_nanf("") : acc[p][e];   // NaN: timed-out hand-off
       }
     }
   }
@@ -215,8 +221,8 @@ __global__ __launch_bounds__(kBlock) void k_bwd_convT(const Group<BwdArgs> G) {
 
 // k_bwd_reduce1 with the transposed conv folded in (MGACBAM_BWD_FOLD): grid of a level = [tile workgroups][nconv conv tiles LAST].
 // The conv tiles start as the streaming workgroups retire and need only the g_pre rows of a few tiles each, so most of the
-// latency-bound conv overlaps the streaming tail and one launch boundary disappears.  Flags: one per k_bwd_reduce1 tile in ctx.sync,
-// 0 before the call (zero-filled by the caller once), set here, cleared again by k_bwd_apply of the same call.
+// latency-bound conv overlaps the streaming tail and one launch boundary disappears.  Flags: one generation counter per k_bwd_reduce1
+// tile and per conv tile in ctx.sync (zero-filled by the caller once, never reset: see bwd_convT_body).
 template <typename T, int VEC, int K>
 __global__ __launch_bounds__(kBlock) void k_bwd_reduce1_fold(const Group<BwdArgs> G) {
   extern __shared__ __align__(16) float smem[];
@@ -576,8 +582,6 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
   const T* xp = static_cast<const T*>(A.x) + base;
   const T* gp = static_cast<const T*>(A.gy) + base;
   T* op = static_cast<T*>(A.gx) + base;
-  if (A.fold && tile == 0)                                     // re-arm MGACBAM_BWD_FOLD's flags of this sample for the next call
-    for (int t = tid; t < ntile; t += kBlock) A.c.sync[A.bflag0 + static_cast<size_t>(b) * A.nflag + t] = 0;
   const float a = softplusf_(*A.p.beta);
   const float N = static_cast<float>(g.HW);
   const bool has_mask = A.mask != nullptr;

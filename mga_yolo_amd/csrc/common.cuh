@@ -198,7 +198,8 @@ __device__ __forceinline__ bool xcd_sample_part(int bid, int B, int P, int& b, i
 //   consumer:  lanes poll the flags (relaxed agent loads, s_sleep) -> s_waitcnt -> barrier -> ld_agent(...) of the data
 // Flags are generation counters: every workgroup bumps its own flag exactly once per call, so after call n a flag reads n;
 // nothing is reset (the region is zero-filled once by the caller) and graph replay needs no per-launch argument.
-// Every spin is bounded: on time-out the error word is set and the workgroup carries on, so the launch always drains.
+// Every spin is bounded: on time-out the status word is set, the workgroup poisons its outputs (NaN) and carries on, so the
+// launch always drains and the failure cannot stay silent.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -211,18 +212,21 @@ __device__ __forceinline__ void handoff_publish(int* flag) {
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// wait until flags[lo..hi] have all reached generation `gen`
-__device__ __forceinline__ void handoff_wait(const int* flags, int lo, int hi, int gen, int* err) {
+// wait until flags[lo..hi] have all reached generation `gen`.  Returns true (uniformly over the workgroup) when a wait timed
+// out: the caller then POISONS what it writes (NaN), so a hand-off that did not happen is loud in the loss, never a silently
+// stale halo; the status word `err` is set as well (read by the host wherever it synchronises: mgacbam_ctx_layout_t.status).
+__device__ __forceinline__ bool handoff_wait(const int* flags, int lo, int hi, int gen, int* err, unsigned spin_limit) {
+  int timed_out = 0;
   for (int t = lo + static_cast<int>(threadIdx.x); t <= hi; t += kBlock) {
     unsigned spins = 0;
     // wrap-safe: the counters run for the life of ctx (2^31 calls = days of training), compare modulo 2^32
     while (static_cast<int>(static_cast<unsigned>(ld_agent(flags + t)) - static_cast<unsigned>(gen)) < 0) {
       __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1u << 20)) { st_agent(err, 1); break; }   // ~1 s: give up, flag it, let the launch drain
+      if (++spins > spin_limit) { st_agent(err, 1); timed_out = 1; break; }   // default 2^20 ~ 1 s: give up, flag it, let the launch drain
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  return __syncthreads_or(timed_out) != 0;
 }
 
 // poor man's thread trace (builds with -DMGACBAM_TRACE, tools/trace_gate.py): thread 0 of a workgroup records the 100 MHz

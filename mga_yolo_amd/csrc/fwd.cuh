@@ -574,9 +574,10 @@ __device__ __forceinline__ void gate_body(const FwdArgs& A, const int bid, float
 
   float* s_ca = smem;
   float* work = s_ca + ((g.C + 3) & ~3);
+  bool bad;                                                    // a hand-off timed out: this tile's sa (hence y) is poisoned with NaN
   {                                                            // ca of this sample: from its role workgroup (gate_role)
     int* caflag = A.c.sync + static_cast<size_t>(g.B) * A.nflag + 4;
-    handoff_wait(caflag, b, b, gen, caflag - 4);
+    bad = handoff_wait(caflag, b, b, gen, caflag - 4, A.spin_limit);
     const float* cab = A.c.ca + static_cast<size_t>(b) * g.C;
     TRACE_MARK(A.trace, gid, 1);                               // ca flag seen
     for (int c = tid; c < g.C; c += kBlock) s_ca[c] = ld_agent(cab + c);
@@ -647,7 +648,7 @@ __device__ __forceinline__ void gate_body(const FwdArgs& A, const int bid, float
   for (int t = tid; t < 3 * k * k; t += kBlock) wts[t] = A.p.wsa[t];
   {
     const int ra = max(r0 - pad, 0), rb = min(r1 + pad, g.H - 1);
-    handoff_wait(flags, (ra * g.W) / TP, ((rb + 1) * g.W - 1) / TP, gen, A.c.sync + static_cast<size_t>(g.B) * A.nflag);
+    bad |= handoff_wait(flags, (ra * g.W) / TP, ((rb + 1) * g.W - 1) / TP, gen, A.c.sync + static_cast<size_t>(g.B) * A.nflag, A.spin_limit);
   }
   TRACE_MARK(A.trace, gid, 6);                                 // neighbours' rows are there
   const float* pl = A.c.planes + static_cast<size_t>(b) * 3 * g.HW;
@@ -687,7 +688,7 @@ __device__ __forceinline__ void gate_body(const FwdArgs& A, const int bid, float
           for (int tj = 0; tj < k; ++tj) acc += wr[tj] * row[tj];
         }
     }
-    const float sa = sigmoidf_(acc);                            // masked_cbam.py:147
+    const float sa = bad ? __builtin_nanf("") : sigmoidf_(acc);   // masked_cbam.py:147 (NaN: loud failure of a timed-out hand-off)
     s_sa[tp] = sa;
     A.c.sa[static_cast<size_t>(b) * g.HW + p] = sa;
   }
@@ -741,7 +742,7 @@ __device__ __forceinline__ void gate_role(const FwdArgs& A, const int b, float* 
     A.c.h_avg[static_cast<size_t>(b) * g.hidden + j] = s_h[j];
     A.c.h_mx[static_cast<size_t>(b) * g.hidden + j] = s_h[g.hidden + j];
   }
-  handoff_publish(caflag);
+  if (!(A.fault && b == 0)) handoff_publish(caflag);           // (fault injection, tests only: sample 0's tiles time out)
   TRACE_MARK(A.trace, blockIdx.x, 5);
 }
 

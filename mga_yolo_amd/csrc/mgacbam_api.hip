@@ -10,6 +10,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "args.cuh"
 #include "bwd.cuh"
@@ -32,8 +36,17 @@ static int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+// Every launch goes through hipLaunchKernel and its OWN return value is checked: the process-wide sticky error state (which
+// may hold an asynchronous error of the framework's kernels on this thread) is neither read nor cleared.
+static thread_local hipError_t g_launch_err = hipSuccess;
+template <typename K, typename A>
+static void launch(K kernel, unsigned grid, size_t smem, hipStream_t st, const A& args) {
+  void* p[] = {const_cast<A*>(&args)};
+  g_launch_err = hipLaunchKernel(reinterpret_cast<const void*>(kernel), dim3(grid), dim3(kBlock), p, smem, st);
+}
 static int launch_status(const char* what) {
-  hipError_t e = hipGetLastError();
+  const hipError_t e = g_launch_err;
+  g_launch_err = hipSuccess;
   if (e != hipSuccess) return fail(static_cast<int>(e), "%s: %s", what, hipGetErrorString(e));
   return 0;
 }
@@ -72,7 +85,8 @@ static void ctx_layout(int B, int C, int H, int W, int hidden, mgacbam_ctx_layou
   L->cidx = take(static_cast<size_t>(B) * HW);
   L->sa = take(static_cast<size_t>(B) * HW);
   L->proj = take(hidden <= MGACBAM_PROJ_MAX_HIDDEN ? static_cast<size_t>(B) * hidden * HW : 0);
-  L->sync = take(2 * static_cast<size_t>(B) * sync_flags(HW) + 4 + B);
+  L->sync = take(3 * static_cast<size_t>(B) * sync_flags(HW) + 4 + B);
+  L->status = L->sync + static_cast<int64_t>(4 * static_cast<size_t>(B) * sync_flags(HW));   // status word 0 (time-out) follows the k_gate tile flags
   L->total = static_cast<int64_t>(o);
 }
 
@@ -101,6 +115,82 @@ static int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   return (s && *s) ? atoi(s) : dflt;
 }
+// Tuning / test knobs come from the environment ONCE (first call) -- not per call: the eager path makes ~50 look-ups per step
+// otherwise.  mgacbam_reload_env() re-reads them (tests and tuning sweeps that change the environment in-process).
+struct Knobs {
+  int gate, chan_mintx, pool_tx, pool_cpt, chan_tx, nt, half_vec, gate_h8, level_order, bwd_fold;
+  int resident_wgs;        // MGACBAM_RESIDENT_WGS: override of the co-resident workgroup budget the hand-off eligibility is sized from
+  int fault;               // MGACBAM_FAULT: fault injection for tests (args.cuh)
+  unsigned spin_limit;     // MGACBAM_SPIN_LIMIT
+  long long* trace;        // MGACBAM_TRACE_PTR (-DMGACBAM_TRACE builds, tools/trace_gate.py)
+};
+static Knobs read_knobs() {
+  Knobs k;
+  k.gate = env_int("MGACBAM_GATE", 1); k.chan_mintx = env_int("MGACBAM_CHAN_MINTX", 16);
+  k.pool_tx = env_int("MGACBAM_POOL_TX", 0); k.pool_cpt = env_int("MGACBAM_POOL_CPT", 0); k.chan_tx = env_int("MGACBAM_CHAN_TX", 0);
+  k.nt = env_int("MGACBAM_NT", 1); k.half_vec = env_int("MGACBAM_HALF_VEC", 4); k.gate_h8 = env_int("MGACBAM_GATE_H8", 1);
+  k.level_order = env_int("MGACBAM_LEVEL_ORDER", 1); k.bwd_fold = env_int("MGACBAM_BWD_FOLD", 1);
+  k.resident_wgs = env_int("MGACBAM_RESIDENT_WGS", 0); k.fault = env_int("MGACBAM_FAULT", 0);
+  const int sl = env_int("MGACBAM_SPIN_LIMIT", 0);
+  k.spin_limit = sl > 0 ? static_cast<unsigned>(sl) : (1u << 20);
+  const char* tp = getenv("MGACBAM_TRACE_PTR");
+  k.trace = (tp && *tp) ? reinterpret_cast<long long*>(strtoull(tp, nullptr, 0)) : nullptr;
+  return k;
+}
+static std::mutex g_knob_mu;
+static Knobs g_knobs;
+static std::atomic<bool> g_knobs_ready{false};
+static Knobs knobs() {
+  if (!g_knobs_ready.load(std::memory_order_acquire)) {
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    if (!g_knobs_ready.load(std::memory_order_relaxed)) { g_knobs = read_knobs(); g_knobs_ready.store(true, std::memory_order_release); }
+  }
+  return g_knobs;   // (written once under the lock before the flag; mgacbam_reload_env is documented as not concurrent with calls)
+}
+extern "C" void mgacbam_reload_env(void) {
+  std::lock_guard<std::mutex> lk(g_knob_mu);
+  g_knobs = read_knobs();
+  g_knobs_ready.store(true, std::memory_order_release);
+}
+
+// Co-resident workgroups of a kernel on the current device = CUs x blocks per CU (occupancy API, for the chosen instantiation and
+// its dynamic LDS).  This is what bounds the in-launch hand-off of k_gate: a tile waits for tiles up to 8*span ids AHEAD, and with
+// in-order dispatch the lowest unfinished workgroup's producers are dispatched iff 8*span + 1 workgroups fit on the device together.
+static int device_cus() {
+  static std::mutex mu;
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  std::lock_guard<std::mutex> lk(mu);
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cus[dev] = n > 0 ? n : -1;
+  }
+  return cus[dev] > 0 ? cus[dev] : 0;
+}
+template <typename K>
+static int resident_workgroups(K kernel, size_t smem) {
+  const int forced = knobs().resident_wgs;
+  if (forced > 0) return forced;
+  static std::mutex mu;
+  static std::map<std::pair<const void*, size_t>, int> cache;
+  const auto key = std::make_pair(reinterpret_cast<const void*>(kernel), smem);
+  int per_cu = -1;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) per_cu = it->second;
+  }
+  if (per_cu < 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlock, smem) != hipSuccess) n = 0;
+    per_cu = n;
+    std::lock_guard<std::mutex> lk(mu);
+    cache[key] = per_cu;
+  }
+  return per_cu * device_cus();
+}
 static bool is_pow2_in(int v, int lo, int hi) { return v >= lo && v <= hi && (v & (v - 1)) == 0; }
 
 // elements per lane per access: 4 (16 B fp32, 8 B fp16/bf16) when the row length allows, else scalar.  8-element (16 B)
@@ -108,7 +198,7 @@ static bool is_pow2_in(int v, int lo, int hi) { return v >= lo && v <= hi && (v 
 // k_chan 19 -> 33 us at YOLOv8n sizes), so they are opt-in for large feature maps only
 static int vec_of(int H, int W, int dtype = MGACBAM_F32) {
   const long long hw = static_cast<long long>(H) * W;
-  if (dtype != MGACBAM_F32 && hw % 8 == 0 && env_int("MGACBAM_HALF_VEC", 4) == 8) return 8;
+  if (dtype != MGACBAM_F32 && hw % 8 == 0 && knobs().half_vec == 8) return 8;
   return hw % 4 == 0 ? 4 : 1;
 }
 
@@ -117,9 +207,9 @@ static int vec_of(int H, int W, int dtype = MGACBAM_F32) {
 // image row, the tiles a k x k window reaches are few (their workgroups must be co-resident: 8 ids apart per tile, common.cuh)
 // and the staged rows fit in LDS; otherwise the three-launch forward runs.
 static void gate_geometry(int C, int H, int W, int k, int VEC, Tune& t) {
-  t.gate_tx = 0; t.gate_rows = 0;
+  t.gate_tx = 0; t.gate_rows = 0; t.gate_span = 0;
   const int gty = pow2_ceil((C + kGateR - 1) / kGateR);
-  if (gty > kBlock || !env_int("MGACBAM_GATE", 1)) return;
+  if (gty > kBlock || !knobs().gate) return;
   const int gtx = kBlock / gty, TP = gtx * VEC;
   int grows = (TP - 1) / W + 2;
   if (grows > H) grows = H;
@@ -128,7 +218,8 @@ static void gate_geometry(int C, int H, int W, int k, int VEC, Tune& t) {
   const size_t lds = (3 * static_cast<size_t>(grows) * (W + k - 1) + TP + 3 * k * k + 3 * C + 64) * sizeof(float);
   // TP >= W: a tile narrower than an image row stages k+1 full rows for a fraction of a row of outputs (measured at
   // 1280-px inputs, C = 256/512: k_gate 220 us against 207 us for k_chan + k_apply; at >= 1.6 rows per tile it wins 18-20 %)
-  if (TP >= kSyncPx && TP >= W && 8 * span <= 256 && lds <= 48 * 1024) { t.gate_tx = gtx; t.gate_rows = grows; }
+  // (whether the 8*span + 1 workgroups a tile's wait spans are co-resident on THIS device is checked at dispatch: forward_group)
+  if (TP >= kSyncPx && TP >= W && lds <= 48 * 1024) { t.gate_tx = gtx; t.gate_rows = grows; t.gate_span = span; }
 }
 
 static Tune choose_tune(int B, int C, int H, int W, int k, int dtype = MGACBAM_F32) {
@@ -142,7 +233,8 @@ static Tune choose_tune(int B, int C, int H, int W, int k, int dtype = MGACBAM_F
   t.pool_tx = tx; t.pool_cpt = cpt;
   // one H*W vector per lane, TY channel slices: TX <= 64 so row reductions are pure wave shuffles
   int ctx = pow2_ceil(nv) < 64 ? pow2_ceil(nv) : 64;
-  const int min_tx = env_int("MGACBAM_CHAN_MINTX", 16);
+  const Knobs kn = knobs();
+  const int min_tx = kn.chan_mintx;
   while (ctx > min_tx && static_cast<long long>(B) * ((nv + ctx - 1) / ctx) < 768) ctx /= 2;
   while (ctx < 64 && (256 / ctx) * 4 > C) ctx *= 2;       // keep >= 4 channels per row
   t.chan_tx = ctx;
@@ -164,14 +256,14 @@ static Tune choose_tune(int B, int C, int H, int W, int k, int dtype = MGACBAM_F
   t.wsa_th = wth;
   // experiment hooks (tests / tuning sweeps); ignored when not a legal value
   int v;
-  if (is_pow2_in(v = env_int("MGACBAM_POOL_TX", 0), 1, 256)) t.pool_tx = v;
-  if ((v = env_int("MGACBAM_POOL_CPT", 0)) == 1 || v == 2 || v == 4) t.pool_cpt = v;
-  if (is_pow2_in(v = env_int("MGACBAM_CHAN_TX", 0), 1, 64)) t.chan_tx = v;
+  if (is_pow2_in(v = kn.pool_tx, 1, 256)) t.pool_tx = v;
+  if ((v = kn.pool_cpt) == 1 || v == 2 || v == 4) t.pool_cpt = v;
+  if (is_pow2_in(v = kn.chan_tx, 1, 64)) t.chan_tx = v;
   // k_apply stages every image row its TX*VEC-pixel tile touches, plus the k-1 halo rows
   int rows = (t.chan_tx * VEC - 1) / W + 2;
   if (rows > H) rows = H;
   t.apply_rows = rows + k - 1;
-  t.nt_stores = env_int("MGACBAM_NT", 1) ? 1 : 0;
+  t.nt_stores = kn.nt ? 1 : 0;
   // k_gate (x-resident chan+apply): every thread keeps kGateR channels, so TY = ceil(C / kGateR) slices (power of two) and the
   // rest of the 256 threads go along H*W.  Eligible when a tile is >= kSyncPx pixels (ctx.sync has one flag per kSyncPx) and >= one image row,
   // the tiles a k x k window reaches are few (their workgroups must be co-resident: 8 ids apart per tile, common.cuh) and
@@ -235,7 +327,7 @@ extern "C" size_t mgacbam_bwd_scratch_bytes(int B, int C, int H, int W, int hidd
 static size_t elem_size(int dtype) { return dtype == MGACBAM_F32 ? 4 : 2; }
 static bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-#define LAUNCH(kernel, grid, smem, stream, args) hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), smem, stream, args)
+#define LAUNCH(kernel, grid, smem, stream, args) launch(kernel, static_cast<unsigned>(grid), smem, stream, args)
 
 // T x VEC
 #define DISPATCH_T_VEC(dtype, VECV, CALL)                                                         \
@@ -275,7 +367,7 @@ struct Sig {
 // k_pool 80 us vs 91 us at config 4, 22 vs 26 us at config 2)
 template <typename Args>
 static int group_cpt(const Args* lv, int n) {
-  const int forced = env_int("MGACBAM_POOL_CPT", 0);
+  const int forced = knobs().pool_cpt;
   if (forced == 1 || forced == 2 || forced == 4) return forced;
   for (int cpt = 2; cpt > 1; cpt /= 2) {
     long long blocks = 0;
@@ -336,7 +428,7 @@ static int forward_args(const mgacbam_fwd_level_t& L, FwdArgs& A, Sig& sig) {
   if (!aligned_to(L.x, need) || !aligned_to(L.y, need) || !aligned_to(L.ctx, 16) || (L.mask && !aligned_to(L.mask, 16)))
     return fail(MGACBAM_E_ALIGN, "forward: x/y must be %zu-byte aligned, ctx 16-byte, mask %d-byte", need, VEC * 4);
   A.x = L.x; A.mask = L.mask; A.y = L.y; A.fused = 0;
-  { const char* tp = getenv("MGACBAM_TRACE_PTR"); A.trace = (tp && *tp) ? reinterpret_cast<long long*>(strtoull(tp, nullptr, 0)) : nullptr; }
+  { const Knobs kn = knobs(); A.trace = kn.trace; A.spin_limit = kn.spin_limit; A.fault = kn.fault; }
   A.nflag = static_cast<int>(sync_flags(static_cast<size_t>(L.H) * L.W));
   A.c = ctx_ptrs(L.ctx, L.B, L.C, L.H, L.W, L.p.hidden);
   A.p = make_params(L.p);
@@ -360,7 +452,7 @@ static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStre
   // fp16 / bf16: k_gate reads 16 bytes per lane (8 elements, kept packed in the registers) whatever vector width the other kernels
   // use -- twice the pixels per tile, half the workgroups: at YOLOv8n sizes the grid then runs as ONE resident round
   int gvec = sig.vec;
-  if (gate && sig.dtype != MGACBAM_F32 && sig.vec == 4 && env_int("MGACBAM_GATE_H8", 1)) {
+  if (gate && sig.dtype != MGACBAM_F32 && sig.vec == 4 && knobs().gate_h8) {
     bool ok8 = true;
     for (int l = 0; l < n && ok8; ++l) {
       Tune t8 = lv[l].t;
@@ -373,6 +465,18 @@ static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStre
     }
   }
   for (int l = 0; l < n && gate; ++l) gate = lv[l].t.gate_tx > 0;
+  size_t gsmem = 0;
+  if (gate) {
+    // residency precondition of the in-launch hand-off, from the DEVICE (CU count x occupancy of the chosen instantiation): the
+    // 8*span + 1 workgroups a tile's wait spans must be co-resident; half of the budget is left to whatever else runs on the chip
+    int span = 0;
+    for (int l = 0; l < n; ++l) { gsmem = std::max(gsmem, gate_smem(lv[l].g, lv[l].t, gvec)); span = std::max(span, lv[l].t.gate_span); }
+    int resident = 0;
+#define RES_GATE(Tt, Vv) resident = (sig.k == 7) ? resident_workgroups(k_gate<Tt, Vv, 7>, gsmem) : resident_workgroups(k_gate<Tt, Vv, 0>, gsmem)
+    DISPATCH_T_VEC(sig.dtype, gvec, RES_GATE);
+#undef RES_GATE
+    gate = 2 * (8 * span + 1) <= resident;
+  }
   if (gate) for (int l = 0; l < n; ++l) { lv[l].fused = 1; G.lv[l].fused = 1; }
 
   if (stages & MGACBAM_FWD_POOL) {  // 1. pooling
@@ -385,8 +489,7 @@ static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStre
     if (int e = launch_status("k_pool")) return e;
   }
   if (gate) {
-    size_t smem = 0;
-    for (int l = 0; l < n; ++l) smem = std::max(smem, gate_smem(lv[l].g, lv[l].t, gvec));
+    const size_t smem = gsmem;
     GateGroup GG;
     const int tiles = fill([&](const FwdArgs& a) { return xcd_grid(a.g.B, gate_tiles(a.t, a.g.H, a.g.W, gvec)); });
     GG.g = G;
@@ -436,7 +539,7 @@ static int for_each_group(Args* args, const Sig* sigs, int n, Run run) {
     int m = 0;
     for (int j = l; j < n && m < kGroupMax; ++j)
       if (!done[j] && sigs[j] == sigs[l]) { grp[m++] = args[j]; done[j] = true; }
-    if (env_int("MGACBAM_LEVEL_ORDER", 1))
+    if (knobs().level_order)
       std::stable_sort(grp, grp + m, [](const Args& a, const Args& b) {
         const int ca = a.g.C * a.t.chan_tx, cb = b.g.C * b.t.chan_tx;   // ~ channels per thread of the tile kernels
         return ca > cb;
@@ -498,9 +601,9 @@ static int backward_args(const mgacbam_bwd_level_t& L, BwdArgs& A, Sig& sig) {
   A.ncg = 0;
   A.nflag = static_cast<int>(sync_flags(static_cast<size_t>(L.H) * L.W));
   A.bflag0 = L.B * A.nflag + 4 + L.B;
+  A.cflag0 = A.bflag0 + L.B * A.nflag;
   A.vec = VEC;
-  A.fold = 0;
-  { const char* tp = getenv("MGACBAM_TRACE_PTR"); A.trace = (tp && *tp) ? reinterpret_cast<long long*>(strtoull(tp, nullptr, 0)) : nullptr; }
+  { const Knobs kn = knobs(); A.trace = kn.trace; A.spin_limit = kn.spin_limit; }
   const int proj = (L.flags & MGACBAM_BWD_HAVE_PROJ) && L.gmask != nullptr;
   A.g.proj_h = (proj && L.p.hidden <= MGACBAM_PROJ_MAX_HIDDEN) ? L.p.hidden : 0;
   sig = Sig{L.dtype, VEC, L.mask != nullptr, L.p.k, L.gmask != nullptr, proj};
@@ -521,12 +624,14 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
 
   // MGACBAM_BWD_FOLD: transposed conv as trailing role workgroups of the k_bwd_reduce1 launch (whole backward in this call, a tile at
   // least one image row and at least kSyncPx pixels -- one flag per tile in ctx.sync -- and few tiles per conv window)
-  bool fold = (stages & MGACBAM_BWD_FOLD) && (stages & MGACBAM_BWD_REDUCE1) && (stages & MGACBAM_BWD_CONVT) && env_int("MGACBAM_BWD_FOLD", 1);
+  // (the conv tiles are the LAST workgroups of the launch and wait only for lower-numbered producers, which never wait themselves:
+  //  progress does not depend on residency; the span bound is a speed heuristic)
+  bool fold = (stages & MGACBAM_BWD_FOLD) && (stages & MGACBAM_BWD_REDUCE1) && (stages & MGACBAM_BWD_CONVT) && knobs().bwd_fold;
   for (int l = 0; l < n && fold; ++l) {
     const int TP = lv[l].t.chan_tx * sig.vec;
-    fold = TP >= kSyncPx && TP >= lv[l].g.W && 8 * (((lv[l].t.conv_th + lv[l].g.k) * lv[l].g.W + TP - 1) / TP + 1) <= 512;
+    fold = TP >= kSyncPx && TP >= lv[l].g.W && 8 * (((lv[l].t.conv_th + lv[l].g.k) * lv[l].g.W + TP - 1) / TP + 1) <= 512 &&
+           lv[l].nconv <= lv[l].g.B * lv[l].nflag;                 // one flag per conv tile fits the region reserved in ctx.sync
   }
-  if (stages & MGACBAM_BWD_FOLD) for (int l = 0; l < n; ++l) { lv[l].fold = 1; G.lv[l].fold = 1; }   // k_bwd_apply clears the flags
   if (fold) {
     size_t smem = 0;
     for (int l = 0; l < n; ++l) smem = std::max({smem, reduce1_smem(lv[l].g, sig.vec), convT_smem(lv[l].t, sig.k)});
@@ -788,8 +893,9 @@ extern "C" int mgacbam_resize_nearest(const float* src, float* dst, int n_planes
   const size_t total = static_cast<size_t>(n_planes) * out_h * out_w;
   size_t grid = (total + kBlock - 1) / kBlock;
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(k_resize_nearest, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                     src, dst, n_planes, in_h, in_w, out_h, out_w);
+  void* kargs[] = {&src, &dst, &n_planes, &in_h, &in_w, &out_h, &out_w};
+  g_launch_err = hipLaunchKernel(reinterpret_cast<const void*>(k_resize_nearest), dim3(static_cast<unsigned>(grid)), dim3(kBlock), kargs, 0,
+                                 static_cast<hipStream_t>(stream));
   if (int e = launch_status("k_resize_nearest")) return e;
   g_err[0] = 0;
   return 0;
@@ -807,6 +913,7 @@ static int seg_check(const mgaseg_level_t* levels, int n, const mgaseg_cfg_t* cf
     if (L.B < 1 || L.H < 1 || L.W < 1 || L.Ht < 1 || L.Wt < 1 || static_cast<long long>(L.H) * L.W > (1ll << 30))
       return fail(MGACBAM_E_SHAPE, "segloss: level %d bad shape B=%d H=%d W=%d Ht=%d Wt=%d", l, L.B, L.H, L.W, L.Ht, L.Wt);
     if (L.dtype != levels[0].dtype || L.dtype < MGACBAM_F32 || L.dtype > MGACBAM_BF16) return fail(MGACBAM_E_DTYPE, "segloss: dtype %d", L.dtype);
+    if (L.resize != MGASEG_NEAREST && L.resize != MGASEG_BILINEAR) return fail(MGACBAM_E_SHAPE, "segloss: level %d resize mode %d", l, L.resize);
   }
   return 0;
 }
@@ -829,6 +936,7 @@ static int seg_args(const mgaseg_level_t* levels, int n, const mgaseg_cfg_t* cfg
     S.sums = S.part + static_cast<size_t>(L.B) * kSegParts * 4;
     w += seg_ws_level(L.B);
     S.B = L.B; S.H = L.H; S.W = L.W; S.Ht = L.Ht; S.Wt = L.Wt; S.w_scale = L.scale_weight;
+    S.bilinear = L.resize == MGASEG_BILINEAR ? 1 : 0;
     A.start[l] = tot;
     tot += L.B * kSegParts;
   }
@@ -873,6 +981,28 @@ extern "C" int mgaseg_backward(const mgaseg_level_t* levels, int n, const mgaseg
   return 0;
 }
 
+extern "C" int mgakendall_forward(const float* det, int n_det, const float* seg, const float* log_vars, float* total, void* stream) {
+  if (!det || !seg || !log_vars || !total) return fail(MGACBAM_E_NULL, "kendall: NULL pointer");
+  if (n_det < 1 || n_det > 4096) return fail(MGACBAM_E_SHAPE, "kendall: n_det=%d", n_det);
+  KendallArgs A{det, seg, log_vars, nullptr, total, nullptr, nullptr, nullptr, n_det};
+  void* p[] = {&A};
+  g_launch_err = hipLaunchKernel(reinterpret_cast<const void*>(k_kendall_fwd), dim3(1), dim3(kWave), p, 0, static_cast<hipStream_t>(stream));
+  if (int e = launch_status("k_kendall_fwd")) return e;
+  g_err[0] = 0;
+  return 0;
+}
+extern "C" int mgakendall_backward(const float* det, int n_det, const float* seg, const float* log_vars, const float* g_total,
+                                   float* g_det, float* g_seg, float* g_log_vars, void* stream) {
+  if (!det || !seg || !log_vars || !g_total || !g_det || !g_seg || !g_log_vars) return fail(MGACBAM_E_NULL, "kendall: NULL pointer");
+  if (n_det < 1 || n_det > 4096) return fail(MGACBAM_E_SHAPE, "kendall: n_det=%d", n_det);
+  KendallArgs A{det, seg, log_vars, g_total, nullptr, g_det, g_seg, g_log_vars, n_det};
+  void* p[] = {&A};
+  g_launch_err = hipLaunchKernel(reinterpret_cast<const void*>(k_kendall_bwd), dim3(1), dim3(kWave), p, 0, static_cast<hipStream_t>(stream));
+  if (int e = launch_status("k_kendall_bwd")) return e;
+  g_err[0] = 0;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // ProbMaskGater
 // ------------------------------------------------------------------------------------------------
@@ -890,7 +1020,7 @@ extern "C" int mgapmg_forward(const float* p, const float* u1, const float* u2, 
   GaterArgs A;
   if (int e = pmg_args(n, cfg, A)) return e;
   A.p = p; A.u1 = u1; A.u2 = u2; A.out = out; A.msoft = msoft;
-  hipLaunchKernelGGL(k_pmg_fwd, dim3(pmg_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), A);
+  LAUNCH(k_pmg_fwd, pmg_grid(n), 0, static_cast<hipStream_t>(stream), A);
   if (int e = launch_status("k_pmg_fwd")) return e;
   g_err[0] = 0;
   return 0;
@@ -901,7 +1031,7 @@ extern "C" int mgapmg_backward(const float* p, const float* msoft, const float* 
   GaterArgs A;
   if (int e = pmg_args(n, cfg, A)) return e;
   A.p = p; A.msoft = const_cast<float*>(msoft); A.gout = gout; A.gp = gp;
-  hipLaunchKernelGGL(k_pmg_bwd, dim3(pmg_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), A);
+  LAUNCH(k_pmg_bwd, pmg_grid(n), 0, static_cast<hipStream_t>(stream), A);
   if (int e = launch_status("k_pmg_bwd")) return e;
   g_err[0] = 0;
   return 0;

@@ -24,6 +24,7 @@ struct SegLevel {
   float* sums;          // (B, 4) per-sample {bce, I, P, T}           (workspace, saved for backward)
   int B, H, W, Ht, Wt;
   float w_scale;
+  int bilinear;         // target resize rule when (Ht,Wt) != (H,W): 0 nearest (segmentation.py:110), 1 bilinear align_corners=False (:103-108)
 };
 struct SegArgs {
   int n;
@@ -39,6 +40,17 @@ struct SegArgs {
 __device__ __forceinline__ float seg_target(const SegLevel& L, int b, int y, int x) {
   if (L.Ht == L.H && L.Wt == L.W) return L.target[(static_cast<size_t>(b) * L.H + y) * L.W + x];
   const float sh = static_cast<float>(L.Ht) / static_cast<float>(L.H), sw = static_cast<float>(L.Wt) / static_cast<float>(L.W);
+  if (L.bilinear) {
+    // F.interpolate(mode="bilinear", align_corners=False): src = max(scale * (dst + 0.5) - 0.5, 0), 4 taps, upper index clamped
+    const float fy = fmaxf(sh * (static_cast<float>(y) + 0.5f) - 0.5f, 0.f), fx = fmaxf(sw * (static_cast<float>(x) + 0.5f) - 0.5f, 0.f);
+    const int y0 = min(static_cast<int>(fy), L.Ht - 1), x0 = min(static_cast<int>(fx), L.Wt - 1);
+    const int y1 = y0 + (y0 < L.Ht - 1 ? 1 : 0), x1 = x0 + (x0 < L.Wt - 1 ? 1 : 0);
+    const float ly = fy - static_cast<float>(y0), lx = fx - static_cast<float>(x0);
+    const float* tb = L.target + static_cast<size_t>(b) * L.Ht * L.Wt;
+    const float top = (1.f - lx) * tb[static_cast<size_t>(y0) * L.Wt + x0] + lx * tb[static_cast<size_t>(y0) * L.Wt + x1];
+    const float bot = (1.f - lx) * tb[static_cast<size_t>(y1) * L.Wt + x0] + lx * tb[static_cast<size_t>(y1) * L.Wt + x1];
+    return (1.f - ly) * top + ly * bot;
+  }
   const int sy = min(static_cast<int>(floorf(static_cast<float>(y) * sh)), L.Ht - 1);
   const int sx = min(static_cast<int>(floorf(static_cast<float>(x) * sw)), L.Wt - 1);
   return L.target[(static_cast<size_t>(b) * L.Ht + sy) * L.Wt + sx];
@@ -168,6 +180,35 @@ __global__ __launch_bounds__(kBlock) void k_seg_bwd(const SegArgs A) {
       const float ddice = -(2.f * t * D - num) * invD2;
       gp[i] = from_f32<T>(kb * (p - t) + kd * ddice * dp);
     }
+  }
+}
+
+// Kendall multi-task combine (mga_yolo/model/model.py:204-206): total[i] = e^{-s0} det[i] + s0 + e^{-s1} seg + s1.  One wave.
+struct KendallArgs {
+  const float* det; const float* seg; const float* log_vars; const float* g_total;
+  float* total; float* g_det; float* g_seg; float* g_log_vars;
+  int n;
+};
+__global__ __launch_bounds__(kWave) void k_kendall_fwd(const KendallArgs A) {
+  const float s0 = A.log_vars[0], s1 = A.log_vars[1];
+  const float seg_term = expf(-s1) * *A.seg + s1;
+  for (int i = threadIdx.x; i < A.n; i += kWave) A.total[i] = expf(-s0) * A.det[i] + s0 + seg_term;
+}
+__global__ __launch_bounds__(kWave) void k_kendall_bwd(const KendallArgs A) {
+  const float s0 = A.log_vars[0], s1 = A.log_vars[1], e0 = expf(-s0), e1 = expf(-s1), seg = *A.seg;
+  float gsum = 0.f, g0 = 0.f;
+  for (int i = threadIdx.x; i < A.n; i += kWave) {
+    const float g = A.g_total[i];
+    A.g_det[i] = g * e0;
+    gsum += g;
+    g0 += g * (1.f - e0 * A.det[i]);
+  }
+  gsum = wave_group_sum(gsum, kWave);
+  g0 = wave_group_sum(g0, kWave);
+  if (threadIdx.x == 0) {
+    *A.g_seg = gsum * e1;
+    A.g_log_vars[0] = g0;
+    A.g_log_vars[1] = gsum * (1.f - e1 * seg);
   }
 }
 

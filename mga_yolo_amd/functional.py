@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -35,7 +36,89 @@ _USE_PROJ = bool(int(os.environ.get("MGACBAM_PROJ", "0")))
 _FUSE_FWD = bool(int(os.environ.get("MGACBAM_FUSE_FWD", "1")))
 # transposed conv folded into the k_bwd_reduce1 launch (MGACBAM_BWD_FOLD); needs the zero-filled ctx tail the fused forward sets up
 _FOLD_BWD = _FUSE_FWD and bool(int(os.environ.get("MGACBAM_FOLD_BWD", "1")))
+# MGACBAM_CHECK_HANDOFF=1: synchronise after every library call and raise if an in-launch hand-off timed out (debugging switch;
+# without it a time-out is still loud -- the tile is poisoned with NaN -- and handoff_report() reads every status word at once)
+_CHECK_HANDOFF = bool(int(os.environ.get("MGACBAM_CHECK_HANDOFF", "0")))
 SLOTS = 8  # tensors per level in the flat argument list: x, mask, w1, b1, w2, b2, wsa, beta
+
+
+class HandoffTimeout(RuntimeError):
+    """An in-launch hand-off (k_gate / folded k_bwd_reduce1) timed out: the device was shared with work that took the CUs its
+    co-residency assumption needs.  The affected tiles were poisoned with NaN.  Set MGACBAM_FUSE_FWD=0 to run without hand-offs."""
+
+
+class _CtxPool:
+    """Saved-statistics buffers of the eager path, recycled per (device, stream, shape): the hand-off flags at the end of ctx are
+    generation counters that are never reset, so a buffer is zero-filled ONCE when it is created and stays consistent over any
+    number of calls -- the per-call zero-fill launch (and the allocation) disappear from the unchanged-trainer path."""
+
+    def __init__(self, keep: int = 8):
+        self.free, self.all, self.keep = {}, [], keep
+
+    def take(self, key, nbytes: int, sync_off: int, dev):
+        lst = self.free.get(key)
+        if lst:
+            return lst.pop()
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        buf[sync_off:].zero_()
+        self.all.append((weakref.ref(buf), key))
+        if len(self.all) > 4096:
+            self.all = [(r, k) for r, k in self.all if r() is not None]
+        return buf
+
+    def give(self, key, buf):
+        lst = self.free.setdefault(key, [])
+        if len(lst) < self.keep:
+            lst.append(buf)
+
+    def clear(self):
+        self.free.clear()
+        self.all = [(r, k) for r, k in self.all if r() is not None]
+
+
+_POOL = _CtxPool()
+
+
+class _Lease:
+    """Returns its buffer to the pool when the autograd context that owns it dies (after backward, or with the graph)."""
+    __slots__ = ("key", "buf")
+
+    def __init__(self, key, buf):
+        self.key, self.buf = key, buf
+
+    def __del__(self):
+        try:
+            _POOL.give(self.key, self.buf)
+        except Exception:
+            pass
+
+
+def handoff_report(clear_pool: bool = False):
+    """Synchronise and read the hand-off status word of every ctx buffer the eager path has handed out and that is still alive.
+    Returns the number of buffers checked; raises HandoffTimeout if any word is set.  Call it where the training loop synchronises
+    anyway (end of an epoch / validation)."""
+    live = [(r(), k) for r, k in _POOL.all]
+    live = [(b, k) for b, k in live if b is not None]
+    if not live:
+        return 0
+    words = []
+    for buf, key in live:
+        _, _, B, Cc, H, W, hidden = key
+        off = _lib.ctx_layout(B, Cc, H, W, hidden)["status"]
+        words.append(buf[off:off + 4].view(torch.int32))
+    bad = [k for (b, k), w in zip(live, torch.cat(words).cpu().tolist()) if w != 0]
+    if clear_pool:
+        _POOL.clear()
+    if bad:
+        raise HandoffTimeout(f"in-launch hand-off timed out for shapes {sorted(set(k[2:6] for k in bad))}")
+    return len(live)
+
+
+def _check_status(bufs_and_shapes, what: str):
+    for buf, (B, Cc, H, W, hidden) in bufs_and_shapes:
+        off = _lib.ctx_layout(B, Cc, H, W, hidden)["status"]
+        if int(buf[off:off + 4].view(torch.int32).item()) != 0:          # (.item() synchronises)
+            raise HandoffTimeout(f"{what}: in-launch hand-off timed out for level (B,C,H,W)=({B},{Cc},{H},{W})")
 
 
 def _aligned(t: torch.Tensor) -> torch.Tensor:
@@ -96,8 +179,11 @@ class _PyramidFn(torch.autograd.Function):
         lib = _lib.load()
         levels = (_lib.FwdLevel * n)()
         keep: List[Optional[torch.Tensor]] = []
-        outs, meta = [], []
+        outs, meta, leases = [], [], []
         dev = flat[0].device
+        if not flat[0].is_cuda:
+            raise RuntimeError("mask_cbam: device tensors only (host tensors take the module's host path)")
+        stream = torch.cuda.current_stream(dev).cuda_stream
         for l in range(n):
             x, mask, *params = flat[l * SLOTS:(l + 1) * SLOTS]
             cfg = cfgs[l]
@@ -109,9 +195,11 @@ class _PyramidFn(torch.autograd.Function):
             m32 = None if mask is None else _mask32(mask, B, H, W)
             pc = [_ready(p) for p in params]
             y = torch.empty_like(xc)
-            cbuf = torch.empty(_lib.ctx_bytes(B, Cc, H, W, cfg.hidden), dtype=torch.uint8, device=dev)
-            if _FUSE_FWD:       # FWD_FUSE contract: the hand-off flags at the end of ctx start at zero
-                cbuf[_lib.ctx_layout(B, Cc, H, W, cfg.hidden)["sync"]:].zero_()
+            # FWD_FUSE / BWD_FOLD contract: the hand-off flags at the end of ctx were zero-filled once (by the pool, at creation)
+            key = (dev.index, stream, B, Cc, H, W, cfg.hidden)
+            lease = _Lease(key, _POOL.take(key, _lib.ctx_bytes(B, Cc, H, W, cfg.hidden), _lib.ctx_layout(B, Cc, H, W, cfg.hidden)["sync"], dev))
+            cbuf = lease.buf
+            leases.append(lease)
             L = levels[l]
             L.x, L.mask, L.y, L.ctx = xc.data_ptr(), (None if m32 is None else m32.data_ptr()), y.data_ptr(), cbuf.data_ptr()
             L.p = _params_struct(pc, cfg)
@@ -120,14 +208,16 @@ class _PyramidFn(torch.autograd.Function):
             # planes for it.  Off by default: at YOLOv8n sizes what k_bwd_apply saves (x of P3) k_chan pays back
             proj = _USE_PROJ and mask is not None and mask.requires_grad and torch.is_grad_enabled()
             L.flags = _lib.FWD_SAVE_PROJ if proj else 0
-            keep += [xc, m32, cbuf, *pc]
+            keep += [xc, m32, *pc]
             outs.append(y)
             meta.append(((None if mask is None else (mask.dtype, tuple(mask.shape))), proj))
         with torch.cuda.device(dev):
             stages = _lib.FWD_ALL | (_lib.FWD_FUSE if _FUSE_FWD else 0)
-            _lib.check(lib.mgacbam_forward_stages(levels, n, stages, torch.cuda.current_stream(dev).cuda_stream), "mgacbam_forward_stages")
+            _lib.check(lib.mgacbam_forward_stages(levels, n, stages, stream), "mgacbam_forward_stages")
+        if _CHECK_HANDOFF:
+            _check_status([(ls.buf, ls.key[2:]) for ls in leases], "mask_cbam forward")
         ctx.save_for_backward(*keep)
-        ctx.cfgs, ctx.meta = cfgs, meta
+        ctx.cfgs, ctx.meta, ctx.leases = cfgs, meta, leases
         return tuple(outs)
 
     @staticmethod
@@ -135,13 +225,14 @@ class _PyramidFn(torch.autograd.Function):
         cfgs, n = ctx.cfgs, len(ctx.cfgs)
         lib = _lib.load()
         saved = ctx.saved_tensors
-        per = 3 + 6
+        per = 2 + 6
         levels = (_lib.BwdLevel * n)()
         grads: List[Optional[torch.Tensor]] = [None]
         hold = []
         dev = saved[0].device
         for l in range(n):
-            xc, m32, cbuf, *pc = saved[l * per:(l + 1) * per]
+            xc, m32, *pc = saved[l * per:(l + 1) * per]
+            cbuf = ctx.leases[l].buf
             cfg = cfgs[l]
             B, Cc, H, W = xc.shape
             gy = gys[l]
@@ -168,6 +259,8 @@ class _PyramidFn(torch.autograd.Function):
             stages = _lib.BWD_ALL | (_lib.BWD_FOLD if _FOLD_BWD else 0)
             _lib.check(lib.mgacbam_backward_stages(levels, n, stages, torch.cuda.current_stream(dev).cuda_stream), "mgacbam_backward_stages")
         del hold
+        if _CHECK_HANDOFF:
+            _check_status([(ls.buf, ls.key[2:]) for ls in ctx.leases], "mask_cbam backward")
         return tuple(grads)
 
 
@@ -217,7 +310,8 @@ def ctx_views(cbuf: torch.Tensor, B, Cc, H, W, hidden) -> dict:
     if hidden <= _lib.PROJ_MAX_HIDDEN:
         shapes["proj"] = (B, hidden, HW)
     nflag = (HW + 15) // 16 + 1
-    shapes["sync"] = (2 * B * nflag + 4 + B,)   # hand-off state: (B, nflag) k_gate flags, [time-out, 3 spare], (B) ca flags, (B, nflag) BWD_FOLD flags
+    # hand-off state: (B, nflag) k_gate flags, [time-out status, 3 spare], (B) ca flags, (B, nflag) BWD_FOLD tile flags, (B, nflag) conv-tile flags
+    shapes["sync"] = (3 * B * nflag + 4 + B,)
     ints = {"valid", "amax", "cidx", "sync"}
     out = {}
     for name, shp in shapes.items():

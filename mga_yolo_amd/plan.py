@@ -17,7 +17,7 @@ import os
 import torch
 
 from . import _lib
-from .functional import BlockConfig, _DTYPES, _params_struct, ctx_views
+from .functional import BlockConfig, HandoffTimeout, _DTYPES, _params_struct, ctx_views
 
 PARAM_NAMES = ("w1", "b1", "w2", "b2", "wsa", "beta")
 
@@ -80,32 +80,49 @@ class PyramidPlan:
             stages |= _lib.FWD_FUSE     # ctx is zero-filled at allocation, as the flag's contract asks
         _lib.check(self.lib.mgacbam_forward_stages(self._fwd, self.n, stages, self._stream()), "mgacbam_forward_stages")
 
+    def check_handoff(self) -> None:
+        """Synchronise and raise HandoffTimeout if any in-launch hand-off of any call on this plan timed out (status word of each
+        level's ctx, include/mgacbam.h).  Callers invoke it where they synchronise anyway: bench.py after the timed region,
+        training loops after a batch of graph replays."""
+        torch.cuda.synchronize(self.device)
+        words = []
+        for l, (B, C, H, W) in enumerate(self.shapes):
+            off = _lib.ctx_layout(B, C, H, W, self.cfgs[l].hidden)["status"]
+            words.append(self.ctx[l][off:off + 4].view(torch.int32))
+        bad = [self.shapes[l] for l, w in enumerate(torch.cat(words).cpu().tolist()) if w != 0]
+        if bad:
+            raise HandoffTimeout(f"in-launch hand-off timed out for levels {bad}: affected tiles were poisoned with NaN "
+                                 "(is the GPU shared with other work?  MGACBAM_FUSE_FWD=0 runs without hand-offs)")
+
     def gate_active(self) -> bool:
         """True when the last fused forward really ran k_gate (the library falls back to k_chan + k_apply for groups with a
         level whose shape is not eligible): k_gate bumps the hand-off flags at the end of ctx, the fallback never touches them."""
         if not self.fuse_forward:
             return False
         torch.cuda.synchronize(self.device)
-        return all(int(self.ctx_view(l)["sync"].max()) > 0 for l in range(self.n))
+        return all(int(self.ctx_view(l)["sync"][:Bn * ((H * W + 15) // 16 + 1)].max()) != 0 for l, (Bn, C, H, W) in enumerate(self.shapes))
 
     def fold_active(self) -> bool:
         """True when MGACBAM_BWD_FOLD really folds the transposed conv into the k_bwd_reduce1 launch for these shapes (the library
-        falls back to two launches for ineligible groups): the folded launch sets the backward hand-off flags, which stay set
-        until the k_bwd_apply of the same backward clears them."""
+        falls back to two launches for ineligible groups): the folded launch bumps the backward hand-off counters."""
         if not self.fold_backward:
             return False
         B = _lib.BWD_STAGES
+
+        def counters():
+            torch.cuda.synchronize(self.device)
+            out = []
+            for l, (Bn, C, H, W) in enumerate(self.shapes):
+                nf = Bn * ((H * W + 15) // 16 + 1)
+                out.append(self.ctx_view(l)["sync"][nf + 4 + Bn:nf + 4 + Bn + nf].clone())
+            return out
         self.forward()
+        before = counters()
         self.backward(B["reduce1"] | B["convT"] | _lib.BWD_FOLD)
+        after = counters()
+        self.backward(_lib.BWD_ALL & ~(B["reduce1"] | B["convT"]))      # finishes the step
         torch.cuda.synchronize(self.device)
-        hit = []
-        for l, (Bn, C, H, W) in enumerate(self.shapes):
-            sync = self.ctx_view(l)["sync"]
-            nf = Bn * ((H * W + 15) // 16 + 1)
-            hit.append(int(sync[nf + 4 + Bn:].max()) > 0)
-        self.backward((_lib.BWD_ALL & ~(B["reduce1"] | B["convT"])) | _lib.BWD_FOLD)      # finishes the step and clears the flags
-        torch.cuda.synchronize(self.device)
-        return all(hit)
+        return all(not torch.equal(a, b) for a, b in zip(before, after))
 
     def backward(self, stages: int = _lib.BWD_ALL):
         if stages == _lib.BWD_ALL and self.fold_backward:

@@ -41,7 +41,7 @@ class _SegFn(torch.autograd.Function):
     """flat = n x (logits, target); returns out = [total, (bce, dice, combined) per level] on the device."""
 
     @staticmethod
-    def forward(ctx, cfg: tuple, weights: Tuple[float, ...], *flat):
+    def forward(ctx, cfg: tuple, weights: Tuple[float, ...], resize: Tuple[int, ...], *flat):
         n = len(flat) // 2
         lib = _lib.load()
         levels = (_lib.SegLevel * n)()
@@ -55,7 +55,7 @@ class _SegFn(torch.autograd.Function):
             L = levels[l]
             L.logits, L.target, L.glogits = xc.data_ptr(), tc.data_ptr(), None
             L.B, L.H, L.W, L.Ht, L.Wt = B, H, W, tc.shape[-2], tc.shape[-1]
-            L.dtype, L.scale_weight = _DTYPE_CODES[xc.dtype], weights[l]
+            L.dtype, L.scale_weight, L.resize = _DTYPE_CODES[xc.dtype], weights[l], resize[l]
             keep += [xc, tc]
         c = _lib.SegCfg(*cfg)
         ws = torch.empty(lib.mgaseg_ws_bytes(levels, n), dtype=torch.uint8, device=dev)
@@ -64,7 +64,7 @@ class _SegFn(torch.autograd.Function):
             _lib.check(lib.mgaseg_forward(levels, n, C.byref(c), ws.data_ptr(), out.data_ptr(),
                                           torch.cuda.current_stream(dev).cuda_stream), "mgaseg_forward")
         ctx.save_for_backward(ws, *keep)
-        ctx.cfg, ctx.weights = cfg, weights
+        ctx.cfg, ctx.weights, ctx.resize = cfg, weights, resize
         return out
 
     @staticmethod
@@ -82,14 +82,14 @@ class _SegFn(torch.autograd.Function):
             L = levels[l]
             L.logits, L.target, L.glogits = xc.data_ptr(), tc.data_ptr(), gx.data_ptr()
             L.B, L.H, L.W, L.Ht, L.Wt = B, H, W, tc.shape[-2], tc.shape[-1]
-            L.dtype, L.scale_weight = _DTYPE_CODES[xc.dtype], ctx.weights[l]
+            L.dtype, L.scale_weight, L.resize = _DTYPE_CODES[xc.dtype], ctx.weights[l], ctx.resize[l]
             grads += [gx, None]
         g0 = gout[0:1].to(torch.float32).contiguous()       # only `total` is differentiable; the log entries are detached copies
         c = _lib.SegCfg(*ctx.cfg)
         with torch.cuda.device(dev):
             _lib.check(lib.mgaseg_backward(levels, n, C.byref(c), ws.data_ptr(), g0.data_ptr(),
                                            torch.cuda.current_stream(dev).cuda_stream), "mgaseg_backward")
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
 def _dice_probs(probs, tgt, smooth):
@@ -133,29 +133,34 @@ class SegmentationLoss(nn.Module):
             pred, tgt = preds[sk], targets[i]
             if tgt.dim() == 3:
                 tgt = tgt.unsqueeze(1)
-            if tgt.shape[-2:] != pred.shape[-2:] and prob_mode:      # probabilistic masks: bilinear, as the reference
-                tgt = F.interpolate(tgt.float(), size=pred.shape[-2:], mode="bilinear", align_corners=False)
             w = cfg.scale_weights[i] if i < len(cfg.scale_weights) else 1.0
             used.append((sk, pred, tgt, float(w)))
         if not used:
             return torch.zeros((), device=first.device, dtype=torch.float32) * cfg.loss_lambda, {"seg_total": 0.0}
-        on_device = all(p.is_cuda for _, p, _, _ in used)
-        same_dtype = len({p.dtype for _, p, _, _ in used}) == 1 and used[0][1].dtype in _DTYPE_CODES
-        if on_device and same_dtype and len(used) <= _lib.SEG_MAX_LEVELS:
-            return self._device_forward(used)
-        return self._torch_forward(used)
+        on_device = [p.is_cuda for _, p, _, _ in used]
+        if all(on_device):
+            # device tensors have no other path.  Levels of different element types (never produced by the reference's layer loop,
+            # which runs all three mask heads under one autocast state) are computed in fp32, like the loss's own accumulators
+            if len({p.dtype for _, p, _, _ in used}) != 1 or used[0][1].dtype not in _DTYPE_CODES:
+                used = [(sk, p.float(), t, w) for sk, p, t, w in used]
+            return self._device_forward(used, prob_mode)
+        if any(on_device):
+            raise RuntimeError("SegmentationLoss: logits of one call must all live on the GPU or all on the host")
+        return self._torch_forward(used, prob_mode)
 
     # ---- HIP path ---------------------------------------------------------------------------------------------------------
-    def _device_forward(self, used):
+    def _device_forward(self, used, prob_mode: bool):
         cfg = self.cfg
         flat = []
+        # targets at another resolution are gathered inside the kernels: nearest, or bilinear for probabilistic masks (segmentation.py:103-110)
+        mode = _lib.SEG_BILINEAR if prob_mode else _lib.SEG_NEAREST
         for _, pred, tgt, _ in used:
             if pred.dim() != 4 or pred.shape[1] != 1 or tgt.shape[0] != pred.shape[0] or tgt.shape[1] != 1:
                 raise RuntimeError(f"SegmentationLoss: logits {tuple(pred.shape)} / target {tuple(tgt.shape)} must be (B,1,H,W)")
             flat += [pred, tgt.to(pred.device)]
         out = _SegFn.apply((float(cfg.bce_weight), float(cfg.dice_weight), float(cfg.smooth), float(cfg.loss_lambda),
                             int(bool(cfg.use_unified_focal)), float(cfg.ufl_lambda), float(cfg.ufl_delta), float(cfg.ufl_gamma)),
-                           tuple(w for *_, w in used), *flat)
+                           tuple(w for *_, w in used), tuple(mode for _ in used), *flat)
         vals = out.detach().cpu().tolist()                          # ONE device->host copy for every log entry
         logs: Dict[str, float] = {}
         for l, (sk, *_rest) in enumerate(used):
@@ -167,13 +172,16 @@ class SegmentationLoss(nn.Module):
         return out[0], logs
 
     # ---- torch ops (host tensors) --------------------------------------------------------------------------
-    def _torch_forward(self, used):
+    def _torch_forward(self, used, prob_mode: bool = False):
         cfg = self.cfg
         total = torch.zeros((), device=used[0][1].device, dtype=torch.float32)
         logs: Dict[str, float] = {}
         for sk, pred, tgt, w in used:
             if tgt.shape[-2:] != pred.shape[-2:]:
-                tgt = F.interpolate(tgt.float(), size=pred.shape[-2:], mode="nearest")
+                if prob_mode:                                       # probabilistic masks: bilinear, as the reference (:103-108)
+                    tgt = F.interpolate(tgt.float(), size=pred.shape[-2:], mode="bilinear", align_corners=False)
+                else:
+                    tgt = F.interpolate(tgt.float(), size=pred.shape[-2:], mode="nearest")
             if cfg.use_unified_focal:
                 a = _lmf(pred.float(), tgt.float(), cfg.ufl_delta, cfg.ufl_gamma)
                 b = _lmft(pred.float(), tgt.float(), cfg.ufl_delta, cfg.ufl_gamma, cfg.smooth)
@@ -190,3 +198,47 @@ class SegmentationLoss(nn.Module):
         total = total * cfg.loss_lambda
         logs["seg_total"] = float(total.detach())
         return total, logs
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Kendall multi-task combine of MGAModel.loss (mga_yolo/model/model.py:204-206)
+# ---------------------------------------------------------------------------------------------------------------------------
+class _KendallFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, det, seg, log_vars):
+        lib = _lib.load()
+        d, s_, lv = det.detach().float().contiguous(), seg.detach().float().reshape(()).contiguous(), log_vars.detach().float().contiguous()
+        total = torch.empty_like(d)
+        with torch.cuda.device(d.device):
+            _lib.check(lib.mgakendall_forward(d.data_ptr(), d.numel(), s_.data_ptr(), lv.data_ptr(), total.data_ptr(),
+                                              torch.cuda.current_stream(d.device).cuda_stream), "mgakendall_forward")
+        ctx.save_for_backward(d, s_, lv)
+        ctx.shapes = (det.shape, seg.shape)
+        return total.view(det.shape)
+
+    @staticmethod
+    def backward(ctx, g_total):
+        d, s_, lv = ctx.saved_tensors
+        lib = _lib.load()
+        g = g_total.float().contiguous()
+        g_det, g_seg, g_lv = torch.empty_like(d), torch.empty_like(s_), torch.empty_like(lv)
+        with torch.cuda.device(d.device):
+            _lib.check(lib.mgakendall_backward(d.data_ptr(), d.numel(), s_.data_ptr(), lv.data_ptr(), g.data_ptr(), g_det.data_ptr(),
+                                               g_seg.data_ptr(), g_lv.data_ptr(), torch.cuda.current_stream(d.device).cuda_stream),
+                       "mgakendall_backward")
+        return g_det.view(ctx.shapes[0]), g_seg.view(ctx.shapes[1]), g_lv
+
+
+def kendall_combine(det_loss: torch.Tensor, seg_total: torch.Tensor, log_vars: torch.Tensor) -> torch.Tensor:
+    """``exp(-s_det) * det_loss + s_det + exp(-s_seg) * seg_total + s_seg`` with ``log_vars = [s_det, s_seg]`` (the learnable
+    ``mtl_log_vars``): the multi-task combine of ``MGAModel.loss`` (mga_yolo/model/model.py:204-206).  ``det_loss`` is the detection
+    criterion's vector (box, cls, dfl), the result has its shape.  Device tensors: one launch forward, one backward
+    (``mgakendall_*``), gradients to det_loss, seg_total and both log-variances; host tensors: the same three torch ops."""
+    if log_vars.numel() != 2:
+        raise ValueError("log_vars must hold [s_det, s_seg]")
+    if det_loss.is_cuda:
+        if not (seg_total.is_cuda and log_vars.is_cuda):
+            raise RuntimeError("kendall_combine: det_loss, seg_total and log_vars must live on the same device")
+        return _KendallFn.apply(det_loss, seg_total, log_vars)
+    s_det, s_seg = log_vars[0], log_vars[1]
+    return torch.exp(-s_det) * det_loss + s_det + torch.exp(-s_seg) * seg_total + s_seg

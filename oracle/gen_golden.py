@@ -130,6 +130,20 @@ BIG = [
     ("cfg2_p3",            32, 64, 80, 80, "sparse", "gy"),
     ("cfg2_p4",            32, 128, 40, 40, "sparse", "gy"),
     ("cfg2_p5",            32, 256, 20, 20, "sparse", "gy"),
+    # BASELINE.json configs[2] (YOLOv8s, 32 images per GPU), configs[3] (YOLOv8m @1280, 8 per GPU), configs[4] (YOLOv8l, mixed 640/1280,
+    # bf16: the reference runs in fp32 on the bf16-rounded inputs), per-GPU batch.  `--big-only` adds them without rewriting the cases.
+    ("cfg3_p3",            32, 128, 80, 80, "sparse", "gy"),
+    ("cfg3_p4",            32, 256, 40, 40, "sparse", "gy"),
+    ("cfg3_p5",            32, 512, 20, 20, "sparse", "gy"),
+    ("cfg4_p3",             8, 256, 160, 160, "sparse", "gy"),
+    ("cfg4_p4",             8, 512, 80, 80, "sparse", "gy"),
+    ("cfg4_p5",             8, 512, 40, 40, "sparse", "gy"),
+    ("cfg5_640_p3",         8, 256, 80, 80, "sparse", "gy_bf16"),
+    ("cfg5_640_p4",         8, 512, 40, 40, "sparse", "gy_bf16"),
+    ("cfg5_640_p5",         8, 512, 20, 20, "sparse", "gy_bf16"),
+    ("cfg5_1280_p3",        4, 256, 160, 160, "sparse", "gy_bf16"),
+    ("cfg5_1280_p4",        4, 512, 80, 80, "sparse", "gy_bf16"),
+    ("cfg5_1280_p5",        4, 512, 40, 40, "sparse", "gy_bf16"),
 ]
 
 
@@ -186,7 +200,12 @@ def checksum(tn):
 def main():
     os.makedirs(OUT, exist_ok=True)
     index = {}
-    for name, B, C, H, W, mk, dk in CASES:
+    big_only = "--big-only" in sys.argv
+    path = os.path.join(OUT, "checksums.json")
+    old = json.load(open(path)) if (big_only and os.path.exists(path)) else {}
+    if big_only:
+        torch.set_num_threads(8)       # checksums only: 1e-4-level comparisons do not depend on the summation order
+    for name, B, C, H, W, mk, dk in ([] if big_only else CASES):
         m = build(C, **mk)
         x, mask, gy = data(B, C, H, W, **dk)
         out, sd = run(m, x, mask, gy)
@@ -203,7 +222,7 @@ def main():
         index[name] = dict(shape=[B, C, H, W], **meta, ysum=float(out["y"].double().sum()))
         print(f"case {name:16s} y.sum={index[name]['ysum']:.6f}")
 
-    for name, B, C, H, W, mk, dk in ECA_CASES:
+    for name, B, C, H, W, mk, dk in ([] if big_only else ECA_CASES):
         m = build_eca(C, **mk)
         x, mask, gy = data(B, C, H, W, **dk)
         out, sd = run_eca(m, x, mask, gy)
@@ -221,18 +240,23 @@ def main():
         index[name] = dict(shape=[B, C, H, W], **meta, ysum=float(out["y"].double().sum()))
         print(f"eca  {name:16s} k={meta['k']} y.sum={index[name]['ysum']:.6f}")
 
-    sums = {}
+    sums = dict(old.get("big", {}))
     for name, B, C, H, W, mkind, recipe in BIG:
+        if big_only and name in sums:
+            continue
         m = build(C)
         x, mask, gy = data(B, C, H, W, mask_kind=mkind)
         if recipe == "ysum":
             gy = torch.ones_like(x)
+        if recipe == "gy_bf16":
+            x, gy = x.bfloat16().float(), gy.bfloat16().float()
         out, _ = run(m, x, mask, gy)
         sums[name] = dict(shape=[B, C, H, W], mask_kind=mkind, recipe=recipe,
                           **{k_: checksum(v) for k_, v in out.items()})
         print(f"big  {name:16s} y.sum={sums[name]['y']['sum']:.6f} |gx|={sums[name]['gx']['abs']:.6f}")
-    with open(os.path.join(OUT, "checksums.json"), "w") as f:
-        json.dump(dict(cases=index, big=sums, torch=torch.__version__), f, indent=1, sort_keys=True)
+    with open(path, "w") as f:
+        json.dump(dict(cases=old.get("cases", index) if big_only else index, big=sums, torch=old.get("torch", torch.__version__)),
+                  f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

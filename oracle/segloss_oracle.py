@@ -4,11 +4,12 @@ Follows mga_yolo/nn/losses/segmentation.py: `_dice_probs` :38-42, `forward` :87-
 soft Dice on sigmoid(pred) :135, scale weights :112, nearest target resize :103-110, loss_lambda :149).  Only tests/,
 __graft_entry__.smoke() and the benchmarks' CPU-baseline leg may import this.
 
-PARITY UNPINNED by reference outputs: the reference file imports Ultralytics' LOGGER at module scope (segmentation.py:7), which
-needs cv2 (not installed, no network), so the class cannot be imported here and none of the reference's files hold outputs for
-it.  What pins this restatement instead: every arithmetic step is a torch op with published semantics (the same ops the
-reference calls), known-answer cases (tests/test_segloss.py) and torch autograd for the gradient.  Unified-Focal mode
-(`use_unified_focal`, off in every shipped config: configs/hyperparams/*.yaml) is restated too (`_lmf` :44-63, `_lmft` :65-85).
+PINNED by outputs of the reference itself: ``oracle/gen_golden_segloss.py`` imported the reference's own ``SegmentationLoss`` in the
+build container (its module-scope LOGGER import needs cv2, absent here; the in-process stand-in of SURVEY appendix A2 satisfies it and
+is never executed) and stored logits, targets, total, every log entry and d total / d logits for 16 cases -- both modes, nearest and
+bilinear (MGA_PROB_MODE) target resize, 3-D targets, missing levels, weights -- in ``tests/golden/segloss_*.npz``; the Kendall combine
+of ``MGAModel.loss`` (model/model.py:204-206), evaluated by the reference model, in ``tests/golden/kendall_*.npz``.
+``tests/test_segloss.py`` checks this restatement against them.  Unified-Focal mode (`_lmf` :44-63, `_lmft` :65-85) is restated too.
 """
 from dataclasses import dataclass
 from typing import Dict, List, Sequence, Tuple
@@ -94,3 +95,9 @@ def forward(preds: Dict[str, torch.Tensor], targets: List[torch.Tensor], cfg: Se
     total = total * cfg.loss_lambda
     logs["seg_total"] = float(total.detach())
     return total, logs
+
+
+def kendall_combine(det_loss: torch.Tensor, seg_total: torch.Tensor, log_vars: torch.Tensor) -> torch.Tensor:
+    """mga_yolo/model/model.py:204-206: L = e^{-s_det} L_det + s_det + e^{-s_seg} L_seg + s_seg (det_loss is the criterion's vector)."""
+    s_det, s_seg = log_vars[0], log_vars[1]
+    return torch.exp(-s_det) * det_loss + s_det + torch.exp(-s_seg) * seg_total + s_seg

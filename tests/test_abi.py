@@ -15,7 +15,7 @@ HEADER = os.path.join(ROOT, "include", "mgacbam.h")
 def declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(mga(?:cbam|seg|pmg)_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(mga(?:cbam|seg|pmg|kendall|head)_\w+)\s*\(", src)))
 
 
 def test_header_declares_the_expected_entry_points():
@@ -65,10 +65,11 @@ def test_ctx_layout_is_packed_aligned_and_ordered(built_lib, shape):
     B, Cc, H, W, hid = shape
     lay = _lib.ctx_layout(B, Cc, H, W, hid)
     assert lay["total"] == _lib.ctx_bytes(B, Cc, H, W, hid)
-    order = [n for n in _lib.CTX_FIELDS if n != "total"]
+    order = [n for n in _lib.CTX_FIELDS if n not in ("total", "status")]
+    assert lay["status"] == lay["sync"] + 4 * B * ((H * W + 15) // 16 + 1)      # the time-out word follows the k_gate tile flags
     sizes = dict(S=B, use=B, den=B, avg=B * Cc, mx=B * Cc, mavg=B * Cc, valid=B * Cc, amax=B * Cc, h_avg=B * hid, h_mx=B * hid,
                  ca=B * Cc, planes=B * 3 * H * W, cidx=B * H * W, sa=B * H * W,
-                 proj=B * hid * H * W if hid <= _lib.PROJ_MAX_HIDDEN else 0, sync=2 * B * ((H * W + 15) // 16 + 1) + 4 + B)
+                 proj=B * hid * H * W if hid <= _lib.PROJ_MAX_HIDDEN else 0, sync=3 * B * ((H * W + 15) // 16 + 1) + 4 + B)
     prev_end = 0
     for n in order:
         assert lay[n] % 16 == 0 and lay[n] >= prev_end, n
@@ -136,5 +137,5 @@ def test_host_tensor_never_reaches_the_device_entry_point(built_lib):
     from mga_yolo_amd import functional
     x = torch.zeros(1, 16, 4, 4)
     ps = [torch.zeros(1, 16), torch.zeros(1), torch.zeros(16, 1), torch.zeros(16), torch.zeros(1, 3, 7, 7), torch.zeros(())]
-    with pytest.raises(RuntimeError, match="same GPU"):
+    with pytest.raises(RuntimeError, match="device tensors only"):
         functional.mask_cbam(x, None, *ps, functional.BlockConfig(hidden=1))

@@ -1,13 +1,84 @@
-"""Multi-scale segmentation loss.  PARITY UNPINNED by reference outputs (the reference class cannot be imported
-here: oracle/segloss_oracle.py header); pinned instead by known answers, by torch's own ops and by torch autograd.
-CPU: the oracle's known answers, the module's host path == the oracle (both modes), reference interface.
-GPU: the HIP entry points (through the module and the C ABI) == the oracle, forward and gradient, incl. nearest target resize."""
+"""Multi-scale segmentation loss.  Pinned by outputs of the reference's own SegmentationLoss / MGAModel.loss
+(tests/golden/segloss_*.npz, kendall_*.npz, written by oracle/gen_golden_segloss.py in the build container).
+CPU: the oracle and the module's host path vs those goldens, known answers, reference interface.
+GPU: the HIP entry points (through the module and the C ABI) vs the goldens and the oracle, forward and gradient, incl. nearest and
+bilinear target resize and the Kendall combine."""
+import json
 import math
+import os
 
+import numpy as np
 import pytest
 import torch
 
+from conftest import GOLDEN
 from oracle import segloss_oracle as O
+
+
+def seg_golden_names():
+    return sorted(f[len("segloss_"):-4] for f in os.listdir(GOLDEN) if f.startswith("segloss_") and f.endswith(".npz"))
+
+
+def load_seg_golden(name):
+    z = np.load(os.path.join(GOLDEN, f"segloss_{name}.npz"), allow_pickle=False)
+    meta = json.loads(bytes(z["meta"]).decode())
+    preds = {k[len("logits."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("logits.")}
+    grads = {k[len("grad."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad.")}
+    targets = [torch.from_numpy(z[f"target.{i}"]) for i in range(sum(1 for k in z.files if k.startswith("target.")))]
+    order = [k for k in ("p3", "p4", "p5") if k in preds]
+    return dict(preds={k: preds[k] for k in order}, grads=grads, targets=targets, meta=meta)
+
+
+def _check_against_golden(d, total, logs, grads, tol_loss=1e-5, tol_grad=1e-4):
+    want = d["meta"]["logs"]
+    assert set(logs) == set(want), (sorted(logs), sorted(want))
+    for k, v in want.items():
+        assert abs(logs[k] - v) <= tol_loss * max(1.0, abs(v)), (k, logs[k], v)
+    assert abs(float(total) - d["meta"]["total"]) <= tol_loss * max(1.0, abs(d["meta"]["total"]))
+    for k, w in d["grads"].items():
+        g = grads[k]
+        g = torch.zeros_like(w) if g is None else g.detach().float().cpu()
+        assert float((g - w).abs().max()) <= tol_grad * float(w.abs().max()) + 1e-9, k
+
+
+@pytest.mark.parametrize("name", seg_golden_names())
+def test_oracle_matches_the_reference_golden(name):
+    d = load_seg_golden(name)
+    cfg = O.SegLossConfig(**d["meta"]["cfg"])
+    leaf = {k: v.float().clone().requires_grad_(True) for k, v in d["preds"].items()}
+    total, logs = O.forward(leaf, d["targets"], cfg, bilinear_targets=d["meta"]["prob_mode"])
+    total.backward()
+    _check_against_golden(d, total.detach(), logs, {k: v.grad for k, v in leaf.items()}, tol_loss=1e-6, tol_grad=1e-6)
+
+
+@pytest.mark.parametrize("name", seg_golden_names())
+def test_module_host_path_matches_the_reference_golden(name, monkeypatch):
+    from mga_yolo_amd.segloss import SegLossConfig, SegmentationLoss
+    d = load_seg_golden(name)
+    if d["meta"]["prob_mode"]:
+        monkeypatch.setenv("MGA_PROB_MODE", "1")
+    else:
+        monkeypatch.delenv("MGA_PROB_MODE", raising=False)
+    leaf = {k: v.float().clone().requires_grad_(True) for k, v in d["preds"].items()}
+    total, logs = SegmentationLoss(SegLossConfig(**d["meta"]["cfg"]))(leaf, d["targets"])
+    total.backward()
+    _check_against_golden(d, total.detach(), logs, {k: v.grad for k, v in leaf.items()}, tol_loss=1e-6, tol_grad=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["init", "trained"])
+def test_kendall_combine_matches_the_reference_model(tag):
+    """MGAModel.loss's multi-task combine as the reference model itself evaluated it (model/model.py:204-206)."""
+    from mga_yolo_amd import kendall_combine
+    z = np.load(os.path.join(GOLDEN, f"kendall_{tag}.npz"))
+    for fn in (O.kendall_combine, kendall_combine):
+        det = torch.from_numpy(z["det_loss"]).clone().requires_grad_(True)
+        seg = torch.from_numpy(z["seg_total"]).clone().requires_grad_(True)
+        lv = torch.from_numpy(z["log_vars"]).clone().requires_grad_(True)
+        total = fn(det, seg, lv)
+        assert torch.allclose(total.detach(), torch.from_numpy(z["total"]), rtol=1e-6, atol=1e-6)
+        total.sum().backward()
+        assert torch.allclose(lv.grad, torch.from_numpy(z["g_log_vars"]), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(det.grad, torch.exp(-lv.detach()[0]).expand(3), rtol=1e-6)
 
 
 def _data(B=3, sizes=((16, 16), (8, 8), (4, 4)), tsize=None, seed=0, dtype=torch.float32):
@@ -139,3 +210,65 @@ def test_device_bad_shapes(built_lib):
     from mga_yolo_amd.segloss import SegLossConfig, SegmentationLoss
     with pytest.raises(RuntimeError):
         SegmentationLoss(SegLossConfig())({"p3": torch.zeros(2, 3, 4, 4).cuda()}, [torch.zeros(2, 1, 4, 4).cuda()])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", seg_golden_names())
+def test_device_path_matches_the_reference_golden(built_lib, name, monkeypatch):
+    """The HIP loss (through the module: C ABI mgaseg_*) against what the reference's own SegmentationLoss produced."""
+    from mga_yolo_amd.segloss import SegLossConfig, SegmentationLoss
+    d = load_seg_golden(name)
+    if d["meta"]["prob_mode"]:
+        monkeypatch.setenv("MGA_PROB_MODE", "1")
+    else:
+        monkeypatch.delenv("MGA_PROB_MODE", raising=False)
+    half = d["meta"]["dtype"] == "float16"
+    leaf = {k: v.cuda().requires_grad_(True) for k, v in d["preds"].items()}
+    total, logs = SegmentationLoss(SegLossConfig(**d["meta"]["cfg"]))(leaf, [t.cuda() for t in d["targets"]])
+    total.backward()
+    _check_against_golden(d, total.detach().cpu(), logs, {k: v.grad for k, v in leaf.items()}, tol_loss=2e-5, tol_grad=2e-3 if half else 1e-4)
+
+
+@pytest.mark.gpu
+def test_device_mixed_dtypes_stay_on_the_device(built_lib):
+    """Levels of different element types are computed in fp32 ON THE DEVICE (no torch-op fallback for device tensors)."""
+    from mga_yolo_amd.segloss import SegLossConfig, SegmentationLoss
+    preds, tg = _data(B=2, seed=4)
+    pd = {"p3": preds["p3"].cuda().half().requires_grad_(True), "p4": preds["p4"].cuda().requires_grad_(True)}
+    crit = SegmentationLoss(SegLossConfig())
+    called = []
+    orig = crit._torch_forward
+    crit._torch_forward = lambda *a, **k: called.append(1) or orig(*a, **k)
+    total, logs = crit(pd, [t.cuda() for t in tg])
+    total.backward()
+    assert not called and pd["p3"].grad.dtype == torch.float16 and pd["p4"].grad.dtype == torch.float32
+    po = {k: v.detach().float().cpu().requires_grad_(True) for k, v in pd.items()}
+    to, _ = O.forward(po, tg, O.SegLossConfig())
+    assert abs(float(total.detach()) - float(to.detach())) < 1e-5 * abs(float(to.detach()))
+    with pytest.raises(RuntimeError):
+        crit({"p3": preds["p3"].cuda(), "p4": preds["p4"]}, [t.cuda() for t in tg])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["init", "trained"])
+def test_device_kendall_combine(built_lib, tag):
+    from mga_yolo_amd import kendall_combine
+    z = np.load(os.path.join(GOLDEN, f"kendall_{tag}.npz"))
+    det = torch.from_numpy(z["det_loss"]).cuda().requires_grad_(True)
+    seg = torch.from_numpy(z["seg_total"]).cuda().requires_grad_(True)
+    lv = torch.from_numpy(z["log_vars"]).cuda().requires_grad_(True)
+    total = kendall_combine(det, seg, lv)
+    assert torch.allclose(total.detach().cpu(), torch.from_numpy(z["total"]), rtol=1e-6, atol=1e-6)
+    w = torch.tensor([1.0, -0.5, 2.0]).cuda()
+    (total * w).sum().backward()
+    e0, e1 = math.exp(-float(z["log_vars"][0])), math.exp(-float(z["log_vars"][1]))
+    dl, sg = torch.from_numpy(z["det_loss"]), float(z["seg_total"])
+    wc = w.cpu()
+    assert torch.allclose(det.grad.cpu(), wc * e0, rtol=1e-6)
+    assert abs(float(seg.grad) - float(wc.sum()) * e1) < 1e-5
+    want0 = float((wc * (1 - e0 * dl)).sum()); want1 = float(wc.sum()) * (1 - e1 * sg)
+    assert abs(float(lv.grad[0]) - want0) < 1e-4 * max(1, abs(want0)) and abs(float(lv.grad[1]) - want1) < 1e-4 * max(1, abs(want1))
+    # the recorded gradient (all-ones upstream) as well
+    det2, seg2, lv2 = (t.detach().clone().requires_grad_(True) for t in (det, seg, lv))
+    kendall_combine(det2, seg2, lv2).sum().backward()
+    assert torch.allclose(lv2.grad.cpu(), torch.from_numpy(z["g_log_vars"]), rtol=1e-5, atol=1e-5)
