@@ -282,7 +282,7 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    if world > ndev:
+    if world > ndev and not os.environ.get("MGACBAM_BENCH_KEEP_HANDOFF"):
         # rehearsal only (several ranks on ONE card): the CUs are shared, so the co-residency the in-launch hand-offs are sized for
         # does not hold -- run the three-launch forward / unfolded backward (what `MGACBAM_FUSE_FWD=0` selects)
         os.environ["MGACBAM_FUSE_FWD"] = "0"

@@ -149,9 +149,15 @@ def load():
         return lib
 
 
+ENV_EPOCH = 0      # bumped by reload_env(): launch geometry may have changed, so pooled hand-off state of older epochs is not reused
+
+
 def reload_env():
     """Make the library re-read its MGACBAM_* knobs (they are read once; tests and tuning sweeps change them in-process)."""
+    global ENV_EPOCH
     load().mgacbam_reload_env()
+    ENV_EPOCH += 1
+    _size_cache.clear()          # scratch sizes depend on the launch geometry (tile counts), which the knobs can change
 
 
 def available() -> bool:

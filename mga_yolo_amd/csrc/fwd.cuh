@@ -60,13 +60,21 @@ __device__ __forceinline__ void pool_body(const FwdArgs& A, const int bid, float
   float sx[CPT], sxs[CPT], vmax[CPT];
   int imax[CPT];
 #pragma unroll
-  for (int j = 0; j < CPT; ++j) { sx[j] = 0.f; sxs[j] = 0.f; vmax[j] = -FLT_MAX; imax[j] = 0; }
+  for (int j = 0; j < CPT; ++j) { sx[j] = 0.f; sxs[j] = 0.f; vmax[j] = -FLT_MAX; imax[j] = 0x7FFFFFFF; }
   float ssum = 0.f;
 
   // PF positions per lane are requested per round: a lane's sweep is a chain of dependent memory rounds (each ~2.5 us
   // under load), so the kernel cannot finish before rounds x latency -- fewer, fatter rounds (profiles/ notes, membw).
+  // Staggered start (t.pool_rot): every workgroup sweeps ITS channels from a different round -- all resident workgroups start
+  // together and advance at the same pace, so un-staggered they all sit at the same offset of planes that lie a fixed stride
+  // apart (25 600 B ... 102 400 B) and their requests crowd onto a fraction of the memory channels.
   constexpr int PF = MGACBAM_POOL_PF;
-  for (int i0 = tx; i0 < nv; i0 += TX * PF) {
+  const int R = (nv + TX * PF - 1) / (TX * PF);               // rounds of this sweep
+  const int rot = A.t.pool_rot ? static_cast<int>((static_cast<unsigned>(cg) * 7u + static_cast<unsigned>(b) * 3u) % static_cast<unsigned>(R)) : 0;
+  for (int kk = 0; kk < R; ++kk) {
+    int k = kk + rot;
+    if (k >= R) k -= R;
+    const int i0 = tx + k * TX * PF;
     float m[PF][VEC], xv[PF][CPT][VEC];
     bool ok[PF];
 #pragma unroll
@@ -101,9 +109,11 @@ __device__ __forceinline__ void pool_body(const FwdArgs& A, const int bid, float
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           const float v = xv[p][j][e];
+          const int idx = i * VEC + e;
           sx[j] += v;
           if (HAS_MASK) sxs[j] += v * s[e];
-          if (sel[e] && v > vmax[j]) { vmax[j] = v; imax[j] = i * VEC + e; }   // strict > : first max wins
+          // first max wins: positions are not visited in increasing order (rot), so equal values compare their indices
+          if (sel[e] && (v > vmax[j] || (v == vmax[j] && idx < imax[j]))) { vmax[j] = v; imax[j] = idx; }
         }
       }
     }
@@ -228,7 +238,7 @@ __device__ __forceinline__ void chan_body(const FwdArgs& A, const int bid, float
   constexpr int HP = kProjMax;
   const Geo& g = A.g;
   const int tid = threadIdx.x;
-  const int TX = A.t.chan_tx, lt = ilog2(TX);
+  const int TX = A.t.chanf_tx, lt = ilog2(TX);
   const int tx = tid & (TX - 1), ty = tid >> lt, TY = kBlock >> lt;
   const int nv = g.HW / VEC;
   const int ntile = (nv + TX - 1) / TX;
@@ -727,20 +737,81 @@ __device__ __forceinline__ void gate_body(const FwdArgs& A, const int bid, float
 // role workgroup of k_gate (one per sample, lowest ids of the launch): the shared MLP, once per sample instead of once per
 // tile -- as a prologue of every tile workgroup its three dependent phases cost 8.7 us per step (ablation), as the tail of
 // k_pool's last arriver 9.4 us; here it runs while the tile workgroups' x loads are in flight.
+// The MLP is a chain of dependent steps (avg/mx -> hidden -> z); fetched step by step every step pays a cross-XCD miss (the
+// operands were written by k_pool's workgroups on other XCDs, the weights are cold), ~5 latencies = 9-14 us, during which this
+// sample's tiles sit on their ca flag.  Here EVERY operand is requested up front -- avg, mx, this wave's W1 rows, this thread's W2
+// row and both biases -- so the chain costs one memory latency plus arithmetic.  The role branch shares k_gate's register
+// allocation (sized by the resident tile), so the ~40 extra registers are free.  Shapes it does not cover (C > 4*64 per wave
+// pass, hidden > kRoleH) use the staged form.
+constexpr int kRoleH = 16;      // hidden units whose W2 entries a thread keeps (C/r with r = 16: C <= 256)
+constexpr int kRoleCW = 4;      // W1 row chunks of 64 channels a lane keeps (C <= 256)
 __device__ __forceinline__ void gate_role(const FwdArgs& A, const int b, float* smem) {
   const Geo& g = A.g;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, C = g.C, h = g.hidden;
+  const int wave = tid >> 6, lane = tid & 63;
   float* s_in = smem;
-  float* s_h = smem + 2 * g.C;
-  float* s_ca = s_h + 2 * g.hidden;
+  float* s_h = smem + 2 * C;
+  float* s_ca = s_h + 2 * h;
   int* caflag = A.c.sync + static_cast<size_t>(g.B) * A.nflag + 4 + b;
   TRACE_MARK(A.trace, blockIdx.x, 0);
-  mlp_gate_to_lds(A, b, false, s_in, s_h, s_ca);
-  TRACE_MARK(A.trace, blockIdx.x, 3);
-  for (int c = tid; c < g.C; c += kBlock) st_agent(A.c.ca + static_cast<size_t>(b) * g.C + c, s_ca[c]);
-  for (int j = tid; j < g.hidden; j += kBlock) {
-    A.c.h_avg[static_cast<size_t>(b) * g.hidden + j] = s_h[j];
-    A.c.h_mx[static_cast<size_t>(b) * g.hidden + j] = s_h[g.hidden + j];
+  const bool fast = C <= kBlock && C <= kRoleCW * kWave && h <= kRoleH && h <= 4 * (kBlock / kWave);
+  if (fast) {
+    const int c = min(tid, C - 1);
+    // ---- issue everything -------------------------------------------------------------------------------------------
+    const float av = A.c.avg[static_cast<size_t>(b) * C + c], mv = A.c.mx[static_cast<size_t>(b) * C + c];
+    float w2r[kRoleH];
+#pragma unroll
+    for (int j = 0; j < kRoleH; ++j) w2r[j] = A.p.w2[static_cast<size_t>(c) * h + min(j, h - 1)];
+    const float b2c = A.p.b2[c];
+    float w1r[4][kRoleCW], b1r[4];                                // hidden units wave, wave+4, wave+8, wave+12
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = min(wave + 4 * q, h - 1);
+      b1r[q] = A.p.b1[j];
+#pragma unroll
+      for (int i = 0; i < kRoleCW; ++i) w1r[q][i] = A.p.w1[static_cast<size_t>(j) * C + min(lane + kWave * i, C - 1)];
+    }
+    if (tid < C) { s_in[tid] = av; s_in[C + tid] = mv; }
+    __syncthreads();
+    // ---- hidden layer: one wave per hidden unit (4 at a time) ----------------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = wave + 4 * q;
+      if (j < h) {                                                // (uniform per wave)
+        float da = 0.f, dm = 0.f;
+#pragma unroll
+        for (int i = 0; i < kRoleCW; ++i) {
+          const int cc = lane + kWave * i;
+          if (cc < C) { da += w1r[q][i] * s_in[cc]; dm += w1r[q][i] * s_in[C + cc]; }
+        }
+        da = wave_group_sum(da, kWave);
+        dm = wave_group_sum(dm, kWave);
+        if (lane == 0) {
+          const float ha = fmaxf(da + b1r[q], 0.f), hm = fmaxf(dm + b1r[q], 0.f);
+          s_h[j] = ha; s_h[h + j] = hm;
+          A.c.h_avg[static_cast<size_t>(b) * h + j] = ha;
+          A.c.h_mx[static_cast<size_t>(b) * h + j] = hm;
+        }
+      }
+    }
+    __syncthreads();
+    TRACE_MARK(A.trace, blockIdx.x, 3);
+    if (tid < C) {
+      float za = 0.f, zm = 0.f;
+#pragma unroll
+      for (int j = 0; j < kRoleH; ++j)
+        if (j < h) { za += w2r[j] * s_h[j]; zm += w2r[j] * s_h[h + j]; }
+      const float z = (za + b2c) + (zm + b2c);                    // same association as mlp_gate_to_lds
+      st_agent(A.c.ca + static_cast<size_t>(b) * C + tid, sigmoidf_(z));
+    }
+  } else {
+    mlp_gate_to_lds(A, b, false, s_in, s_h, s_ca);
+    TRACE_MARK(A.trace, blockIdx.x, 3);
+    for (int c = tid; c < C; c += kBlock) st_agent(A.c.ca + static_cast<size_t>(b) * C + c, s_ca[c]);
+    for (int j = tid; j < h; j += kBlock) {
+      A.c.h_avg[static_cast<size_t>(b) * h + j] = s_h[j];
+      A.c.h_mx[static_cast<size_t>(b) * h + j] = s_h[h + j];
+    }
   }
   if (!(A.fault && b == 0)) handoff_publish(caflag);           // (fault injection, tests only: sample 0's tiles time out)
   TRACE_MARK(A.trace, blockIdx.x, 5);

@@ -118,7 +118,7 @@ static int env_int(const char* name, int dflt) {
 // Tuning / test knobs come from the environment ONCE (first call) -- not per call: the eager path makes ~50 look-ups per step
 // otherwise.  mgacbam_reload_env() re-reads them (tests and tuning sweeps that change the environment in-process).
 struct Knobs {
-  int gate, chan_mintx, pool_tx, pool_cpt, chan_tx, nt, half_vec, gate_h8, level_order, bwd_fold;
+  int gate, chan_mintx, pool_tx, pool_cpt, chan_tx, chanf_tx, nt, half_vec, gate_h8, level_order, bwd_fold, pool_rot;
   int resident_wgs;        // MGACBAM_RESIDENT_WGS: override of the co-resident workgroup budget the hand-off eligibility is sized from
   int fault;               // MGACBAM_FAULT: fault injection for tests (args.cuh)
   unsigned spin_limit;     // MGACBAM_SPIN_LIMIT
@@ -130,6 +130,7 @@ static Knobs read_knobs() {
   k.pool_tx = env_int("MGACBAM_POOL_TX", 0); k.pool_cpt = env_int("MGACBAM_POOL_CPT", 0); k.chan_tx = env_int("MGACBAM_CHAN_TX", 0);
   k.nt = env_int("MGACBAM_NT", 1); k.half_vec = env_int("MGACBAM_HALF_VEC", 4); k.gate_h8 = env_int("MGACBAM_GATE_H8", 1);
   k.level_order = env_int("MGACBAM_LEVEL_ORDER", 1); k.bwd_fold = env_int("MGACBAM_BWD_FOLD", 1);
+  k.pool_rot = env_int("MGACBAM_POOL_ROT", 1); k.chanf_tx = env_int("MGACBAM_CHANF_TX", 0);
   k.resident_wgs = env_int("MGACBAM_RESIDENT_WGS", 0); k.fault = env_int("MGACBAM_FAULT", 0);
   const int sl = env_int("MGACBAM_SPIN_LIMIT", 0);
   k.spin_limit = sl > 0 ? static_cast<unsigned>(sl) : (1u << 20);
@@ -224,16 +225,16 @@ static void gate_geometry(int C, int H, int W, int k, int VEC, Tune& t) {
 
 static Tune choose_tune(int B, int C, int H, int W, int k, int dtype = MGACBAM_F32) {
   const int HW = H * W, VEC = vec_of(H, W, dtype), nv = HW / VEC;
+  const Knobs kn = knobs();
   Tune t;
   // rows of TX lanes sweep H*W: aim for >= 4 sweeps per lane, then shrink channels/row until the grid fills the chip
   int tx = pow2_floor(nv / 4 > 0 ? nv / 4 : 1);
   if (tx > 256) tx = 256;
   int cpt = 4;
   while (cpt > 1 && static_cast<long long>(B) * ((C + (256 / tx) * cpt - 1) / ((256 / tx) * cpt)) < 1024) cpt /= 2;
-  t.pool_tx = tx; t.pool_cpt = cpt;
+  t.pool_tx = tx; t.pool_cpt = cpt; t.pool_rot = kn.pool_rot ? 1 : 0;
   // one H*W vector per lane, TY channel slices: TX <= 64 so row reductions are pure wave shuffles
   int ctx = pow2_ceil(nv) < 64 ? pow2_ceil(nv) : 64;
-  const Knobs kn = knobs();
   const int min_tx = kn.chan_mintx;
   while (ctx > min_tx && static_cast<long long>(B) * ((nv + ctx - 1) / ctx) < 768) ctx /= 2;
   while (ctx < 64 && (256 / ctx) * 4 > C) ctx *= 2;       // keep >= 4 channels per row
@@ -259,6 +260,8 @@ static Tune choose_tune(int B, int C, int H, int W, int k, int dtype = MGACBAM_F
   if (is_pow2_in(v = kn.pool_tx, 1, 256)) t.pool_tx = v;
   if ((v = kn.pool_cpt) == 1 || v == 2 || v == 4) t.pool_cpt = v;
   if (is_pow2_in(v = kn.chan_tx, 1, 64)) t.chan_tx = v;
+  t.chanf_tx = t.chan_tx;
+  if (is_pow2_in(v = kn.chanf_tx, 1, 64)) t.chanf_tx = v;
   // k_apply stages every image row its TX*VEC-pixel tile touches, plus the k-1 halo rows
   int rows = (t.chan_tx * VEC - 1) / W + 2;
   if (rows > H) rows = H;
@@ -505,7 +508,7 @@ static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStre
   if (stages & MGACBAM_FWD_CHAN) {  // 2. shared MLP + channel gate (prologue), channel max / mean planes
     size_t smem = 0;
     for (int l = 0; l < n; ++l) smem = std::max(smem, chan_smem(lv[l].g, sig.vec, sig.proj));
-    const int grid = fill([&](const FwdArgs& a) { return xcd_grid(a.g.B, chan_tiles(a.t, a.g.H, a.g.W, sig.vec)); });
+    const int grid = fill([&](const FwdArgs& a) { return xcd_grid(a.g.B, (a.g.HW / sig.vec + a.t.chanf_tx - 1) / a.t.chanf_tx); });
 #define CALL_CHAN(Tt, Vv) if (sig.proj) LAUNCH((k_chan<Tt, Vv, true>), grid, smem, st, G); else LAUNCH((k_chan<Tt, Vv, false>), grid, smem, st, G)
     DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_CHAN);
 #undef CALL_CHAN

@@ -103,14 +103,15 @@ def handoff_report(clear_pool: bool = False):
         return 0
     words = []
     for buf, key in live:
-        _, _, B, Cc, H, W, hidden = key
+        B, Cc, H, W, hidden = key[2:7]
         off = _lib.ctx_layout(B, Cc, H, W, hidden)["status"]
         words.append(buf[off:off + 4].view(torch.int32))
     bad = [k for (b, k), w in zip(live, torch.cat(words).cpu().tolist()) if w != 0]
     if clear_pool:
         _POOL.clear()
     if bad:
-        raise HandoffTimeout(f"in-launch hand-off timed out for shapes {sorted(set(k[2:6] for k in bad))}")
+        raise HandoffTimeout(f"in-launch hand-off timed out for shapes {sorted(set(k[2:6] for k in bad))}: affected tiles were "
+                             "poisoned with NaN (is the GPU shared with other work?  MGACBAM_FUSE_FWD=0 runs without hand-offs)")
     return len(live)
 
 
@@ -196,7 +197,8 @@ class _PyramidFn(torch.autograd.Function):
             pc = [_ready(p) for p in params]
             y = torch.empty_like(xc)
             # FWD_FUSE / BWD_FOLD contract: the hand-off flags at the end of ctx were zero-filled once (by the pool, at creation)
-            key = (dev.index, stream, B, Cc, H, W, cfg.hidden)
+            # (the flags count calls PER TILE, so a buffer is only reused under the tiling it was used with: same element type, same knobs)
+            key = (dev.index, stream, B, Cc, H, W, cfg.hidden, x.dtype, _lib.ENV_EPOCH)
             lease = _Lease(key, _POOL.take(key, _lib.ctx_bytes(B, Cc, H, W, cfg.hidden), _lib.ctx_layout(B, Cc, H, W, cfg.hidden)["sync"], dev))
             cbuf = lease.buf
             leases.append(lease)
@@ -215,7 +217,7 @@ class _PyramidFn(torch.autograd.Function):
             stages = _lib.FWD_ALL | (_lib.FWD_FUSE if _FUSE_FWD else 0)
             _lib.check(lib.mgacbam_forward_stages(levels, n, stages, stream), "mgacbam_forward_stages")
         if _CHECK_HANDOFF:
-            _check_status([(ls.buf, ls.key[2:]) for ls in leases], "mask_cbam forward")
+            _check_status([(ls.buf, ls.key[2:7]) for ls in leases], "mask_cbam forward")
         ctx.save_for_backward(*keep)
         ctx.cfgs, ctx.meta, ctx.leases = cfgs, meta, leases
         return tuple(outs)
@@ -260,7 +262,7 @@ class _PyramidFn(torch.autograd.Function):
             _lib.check(lib.mgacbam_backward_stages(levels, n, stages, torch.cuda.current_stream(dev).cuda_stream), "mgacbam_backward_stages")
         del hold
         if _CHECK_HANDOFF:
-            _check_status([(ls.buf, ls.key[2:]) for ls in ctx.leases], "mask_cbam backward")
+            _check_status([(ls.buf, ls.key[2:7]) for ls in ctx.leases], "mask_cbam backward")
         return tuple(grads)
 
 
