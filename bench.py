@@ -175,7 +175,11 @@ def eager_module_step(workload, device, dtype_name, steps=60, warmup=10):
         gy = torch.randn(batch, C, H, W, generator=g).to(device, dt)
         data.append((x, m, gy))
 
+    leaves = [t for x, m, _ in data for t in (x, m)] + [p for mod in mods for p in mod.parameters()]
+
     def step():
+        for t in leaves:                                         # optimizer.zero_grad(set_to_none=True), as the reference trainer does every
+            t.grad = None                                        # step (otherwise autograd adds into the old gradients: 24 extra kernels)
         ys = [mod([x, m]) for mod, (x, m, _) in zip(mods, data)]
         torch.autograd.backward(ys, [gy for _, _, gy in data])
     for _ in range(warmup):

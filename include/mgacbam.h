@@ -17,7 +17,8 @@
  *     every accumulator and every saved statistic are fp32).
  *
  * Entry-point families: mgacbam_*  MaskCBAM (the hot path) + mgacbam_eca_* MaskECA + mgacbam_resize_nearest;
- *                       mgaseg_*   multi-scale segmentation loss;   mgapmg_*  ProbMaskGater's Gumbel gate.
+ *                       mgahead_*  MGAMaskHead (the mask producer);  mgaseg_* multi-scale segmentation loss + mgakendall_* combine;
+ *                       mgapmg_*   ProbMaskGater's Gumbel gate.
  */
 #ifndef MGACBAM_H_
 #define MGACBAM_H_
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MGACBAM_ABI_VERSION 9
+#define MGACBAM_ABI_VERSION 10
 #define MGACBAM_MAX_LEVELS 8          /* P3/P4/P5 need 3 */
 
 enum { MGACBAM_F32 = 0, MGACBAM_F16 = 1, MGACBAM_BF16 = 2 };
@@ -273,6 +274,57 @@ size_t mgaseg_ws_bytes(const mgaseg_level_t* levels, int n_levels);   /* workspa
 int mgaseg_forward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, void* ws, float* out, void* stream);
 /* gout: device scalar dL/d(total) */
 int mgaseg_backward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, const void* ws, const float* gout, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * MGAMaskHead: the producer of the mask logits, mga_yolo/nn/modules/segmentation.py:56-110 in its default configuration
+ * (norm="bn", act=SiLU, dropout=0, out_channels=1):  Conv1x1(C -> hidden, no bias) -> BatchNorm2d -> SiLU -> Conv3x3(hidden -> 1) + bias,
+ * and its autograd backward.  The 1x1 conv and its two backward products run on the matrix cores (fp32 MFMA 16x16x4).  Parameters are
+ * the reference's state_dict entries, fp32, contiguous, on the device.  training != 0: BatchNorm uses batch statistics and updates
+ * running_mean / running_var (momentum) and num_batches_tracked in place, as torch does; training == 0: running statistics, no update.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mgahead_params {
+  const float* w1;             /* proj.0.weight (hidden, C, 1, 1)          segmentation.py:81 */
+  const float* bn_weight;      /* proj.1.weight (hidden)                   :83                */
+  const float* bn_bias;        /* proj.1.bias (hidden)                                        */
+  float* running_mean;         /* proj.1.running_mean (hidden), updated when training         */
+  float* running_var;          /* proj.1.running_var (hidden)                                 */
+  int64_t* num_batches_tracked;/* proj.1.num_batches_tracked () int64, or NULL                */
+  const float* wh;             /* head.weight (1, hidden, 3, 3)            :92                */
+  const float* bh;             /* head.bias (1)                                               */
+  int32_t hidden;
+  float eps, momentum;         /* BatchNorm2d.eps / .momentum (Ultralytics sets 1e-3 / 0.03: U/utils/torch_utils.py:570-572) */
+  int32_t training;
+} mgahead_params_t;
+
+typedef struct mgahead_fwd_level {
+  const void* x;               /* (B,C,H,W) feature of `dtype`                                 */
+  void* logits;                /* (B,1,H,W) mask logits of `dtype`                             */
+  void* ctx;                   /* mgahead_ctx_bytes(): z, batch statistics (kept for backward) */
+  mgahead_params_t p;
+  int32_t B, C, H, W;
+  int32_t dtype;
+} mgahead_fwd_level_t;
+
+typedef struct mgahead_bwd_level {
+  const void* x;               /* as in forward                                                */
+  const void* g_logits;        /* (B,1,H,W) dL/dlogits of `dtype`                              */
+  const void* ctx;             /* written by the matching forward                              */
+  void* scratch;               /* mgahead_bwd_scratch_bytes(), contents undefined              */
+  void* gx;                    /* (B,C,H,W) dL/dx of `dtype`                                   */
+  float* gw1;                  /* parameter gradients, shapes of the parameters, OVERWRITTEN   */
+  float* gbn_weight;
+  float* gbn_bias;
+  float* gwh;
+  float* gbh;
+  mgahead_params_t p;          /* training as in the forward; running statistics are not touched */
+  int32_t B, C, H, W;
+  int32_t dtype;
+} mgahead_bwd_level_t;
+
+size_t mgahead_ctx_bytes(int B, int C, int H, int W, int hidden);
+size_t mgahead_bwd_scratch_bytes(int B, int C, int H, int W, int hidden);
+int mgahead_forward(const mgahead_fwd_level_t* levels, int n_levels, void* stream);     /* 3 launches for all levels */
+int mgahead_backward(const mgahead_bwd_level_t* levels, int n_levels, void* stream);    /* 5 launches for all levels */
 
 /* Kendall multi-task combine of MGAModel.loss (mga_yolo/model/model.py:204-206), on the device so that no loss value has to visit
  * the host:  total[i] = exp(-s_det) * det[i] + s_det + exp(-s_seg) * seg + s_seg   for the n_det entries of the detection-loss vector

@@ -7,11 +7,11 @@
 Layout: ``csrc/`` hand-written HIP kernels + the C ABI of ``include/mgacbam.h``; ``_lib`` ctypes binding (no fallback);
 ``functional`` autograd entry points; ``module`` the nn.Module mirror; ``dp`` data-parallel gradient exchange (RCCL).
 """
-from .functional import BlockConfig, EcaConfig, HandoffTimeout, handoff_report, mask_cbam, mask_cbam_pyramid, mask_eca, mask_eca_pyramid, prob_mask_gate, resize_nearest  # noqa: F401
+from .functional import BlockConfig, EcaConfig, HandoffTimeout, handoff_report, mask_cbam, mask_cbam_pyramid, mask_eca, mask_eca_pyramid, mask_head, mask_head_pyramid, prob_mask_gate, resize_nearest  # noqa: F401
 from .install import install, uninstall  # noqa: F401
-from .module import MaskCBAM, MaskECA, ProbMaskGater  # noqa: F401
+from .module import MGAMaskHead, MaskCBAM, MaskECA, ProbMaskGater  # noqa: F401
 from .segloss import SegLossConfig, SegmentationLoss, kendall_combine  # noqa: F401
 
-__all__ = ["MaskCBAM", "MaskECA", "ProbMaskGater", "BlockConfig", "EcaConfig", "mask_cbam", "mask_cbam_pyramid", "mask_eca",
+__all__ = ["MaskCBAM", "MaskECA", "MGAMaskHead", "mask_head", "mask_head_pyramid", "ProbMaskGater", "BlockConfig", "EcaConfig", "mask_cbam", "mask_cbam_pyramid", "mask_eca",
            "mask_eca_pyramid", "prob_mask_gate", "resize_nearest", "install", "uninstall", "SegLossConfig", "SegmentationLoss", "kendall_combine", "HandoffTimeout", "handoff_report"]
 __version__ = "0.1.0"

@@ -8,7 +8,7 @@ import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGACBAM_LIB") or os.path.join(_PKG, "libmgacbam.so")   # MGACBAM_LIB: A/B builds in tuning sweeps
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_LEVELS = 8
 F32, F16, BF16 = 0, 1, 2
 # stage bit masks (include/mgacbam.h)
@@ -84,6 +84,23 @@ SEG_MAX_LEVELS = 4
 SEG_NEAREST, SEG_BILINEAR = 0, 1
 
 
+class HeadParams(C.Structure):                   # mgahead_params_t
+    _fields_ = [("w1", C.c_void_p), ("bn_weight", C.c_void_p), ("bn_bias", C.c_void_p), ("running_mean", C.c_void_p),
+                ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("wh", C.c_void_p), ("bh", C.c_void_p),
+                ("hidden", C.c_int32), ("eps", C.c_float), ("momentum", C.c_float), ("training", C.c_int32)]
+
+
+class HeadFwdLevel(C.Structure):                 # mgahead_fwd_level_t
+    _fields_ = [("x", C.c_void_p), ("logits", C.c_void_p), ("ctx", C.c_void_p), ("p", HeadParams),
+                ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dtype", C.c_int32)]
+
+
+class HeadBwdLevel(C.Structure):                 # mgahead_bwd_level_t
+    _fields_ = [("x", C.c_void_p), ("g_logits", C.c_void_p), ("ctx", C.c_void_p), ("scratch", C.c_void_p), ("gx", C.c_void_p),
+                ("gw1", C.c_void_p), ("gbn_weight", C.c_void_p), ("gbn_bias", C.c_void_p), ("gwh", C.c_void_p), ("gbh", C.c_void_p),
+                ("p", HeadParams), ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dtype", C.c_int32)]
+
+
 class PmgCfg(C.Structure):                       # mgapmg_cfg_t
     _fields_ = [("tau", C.c_float), ("p_min", C.c_float), ("threshold", C.c_float), ("hard", C.c_int32)]
 
@@ -108,6 +125,10 @@ SYMBOLS = {
     "mgaseg_ws_bytes": (C.c_size_t, [C.POINTER(SegLevel), C.c_int]),
     "mgaseg_forward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgaseg_backward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgahead_ctx_bytes": (C.c_size_t, [C.c_int] * 5),
+    "mgahead_bwd_scratch_bytes": (C.c_size_t, [C.c_int] * 5),
+    "mgahead_forward": (C.c_int, [C.POINTER(HeadFwdLevel), C.c_int, C.c_void_p]),
+    "mgahead_backward": (C.c_int, [C.POINTER(HeadBwdLevel), C.c_int, C.c_void_p]),
     "mgakendall_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgakendall_backward": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 7),
     "mgapmg_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_size_t, C.POINTER(PmgCfg), C.c_void_p]),

@@ -34,7 +34,6 @@ struct ParamPtrs { const float* w1; const float* b1; const float* w2; const floa
 struct Tune {
   int pool_tx;     // sweep kernels (k_pool, k_bwd_reduce2, k_eca_*): rows of TX lanes sweep H*W, TY = 256/TX rows x CPT channels
   int pool_cpt;
-  int pool_rot;    // 1: every sweep workgroup starts at a different round of its H*W sweep (spreads concurrent requests over the memory channels)
   int chan_tx;     // tile kernels (k_chan, k_apply, k_bwd_reduce1, k_bwd_apply, k_eca_bwd): one H*W vector per lane, TY = 256/TX channel slices
   int chanf_tx;    // k_chan alone (its tiles are independent of every other kernel's): TX lanes along H*W
   int conv_twq;    // backward conv tiles: TWQ quads (4 px) wide, TH rows

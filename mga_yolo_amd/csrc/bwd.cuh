@@ -351,12 +351,7 @@ __device__ __forceinline__ void bwd_reduce2_body(const BwdArgs& A, const int bid
   for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
 
   constexpr int PF = MGACBAM_POOL_PF;                         // positions per lane per memory round (see k_pool)
-  const int R = (nv + TX * PF - 1) / (TX * PF);
-  const int rot = A.t.pool_rot ? static_cast<int>((static_cast<unsigned>(cg) * 7u + static_cast<unsigned>(b) * 3u) % static_cast<unsigned>(R)) : 0;   // staggered start, as k_pool
-  for (int kk = 0; kk < R; ++kk) {
-    int k = kk + rot;
-    if (k >= R) k -= R;
-    const int i0 = tx + k * TX * PF;
+  for (int i0 = tx; i0 < nv; i0 += TX * PF) {
     float g0[PF][VEC], g1[PF][VEC], xv[PF][CPT][VEC];
     int ci[PF][VEC];
     bool ok[PF];

@@ -60,21 +60,15 @@ __device__ __forceinline__ void pool_body(const FwdArgs& A, const int bid, float
   float sx[CPT], sxs[CPT], vmax[CPT];
   int imax[CPT];
 #pragma unroll
-  for (int j = 0; j < CPT; ++j) { sx[j] = 0.f; sxs[j] = 0.f; vmax[j] = -FLT_MAX; imax[j] = 0x7FFFFFFF; }
+  for (int j = 0; j < CPT; ++j) { sx[j] = 0.f; sxs[j] = 0.f; vmax[j] = -FLT_MAX; imax[j] = 0; }
   float ssum = 0.f;
 
   // PF positions per lane are requested per round: a lane's sweep is a chain of dependent memory rounds (each ~2.5 us
   // under load), so the kernel cannot finish before rounds x latency -- fewer, fatter rounds (profiles/ notes, membw).
-  // Staggered start (t.pool_rot): every workgroup sweeps ITS channels from a different round -- all resident workgroups start
-  // together and advance at the same pace, so un-staggered they all sit at the same offset of planes that lie a fixed stride
-  // apart (25 600 B ... 102 400 B) and their requests crowd onto a fraction of the memory channels.
   constexpr int PF = MGACBAM_POOL_PF;
-  const int R = (nv + TX * PF - 1) / (TX * PF);               // rounds of this sweep
-  const int rot = A.t.pool_rot ? static_cast<int>((static_cast<unsigned>(cg) * 7u + static_cast<unsigned>(b) * 3u) % static_cast<unsigned>(R)) : 0;
-  for (int kk = 0; kk < R; ++kk) {
-    int k = kk + rot;
-    if (k >= R) k -= R;
-    const int i0 = tx + k * TX * PF;
+  // (A staggered start -- every workgroup beginning its sweep at a different round, to spread concurrent requests over the memory
+  //  channels -- was measured at configs 2, 3, 4: no gain, k_bwd_reduce2 10 % slower from the extra index arithmetic; not kept.)
+  for (int i0 = tx; i0 < nv; i0 += TX * PF) {
     float m[PF][VEC], xv[PF][CPT][VEC];
     bool ok[PF];
 #pragma unroll
@@ -109,11 +103,9 @@ __device__ __forceinline__ void pool_body(const FwdArgs& A, const int bid, float
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           const float v = xv[p][j][e];
-          const int idx = i * VEC + e;
           sx[j] += v;
           if (HAS_MASK) sxs[j] += v * s[e];
-          // first max wins: positions are not visited in increasing order (rot), so equal values compare their indices
-          if (sel[e] && (v > vmax[j] || (v == vmax[j] && idx < imax[j]))) { vmax[j] = v; imax[j] = idx; }
+          if (sel[e] && v > vmax[j]) { vmax[j] = v; imax[j] = i * VEC + e; }   // strict > : first max wins
         }
       }
     }
@@ -232,7 +224,7 @@ __device__ __forceinline__ void mlp_gate_to_lds(const FwdArgs& A, const int b, c
 //   P[b,j,hw] = sum_c W1[j,c] x[b,c,hw] (hidden <= kProjMax), so that k_bwd_apply never has to read x (see bwd.cuh).
 //   LDS: [2C scratch][2h][C ca][C*kProjMax W1^T (PROJ)][4*256*VEC combine]
 // ---------------------------------------------------------------------------------------------
-template <typename T, int VEC, bool PROJ>
+template <typename T, int VEC, bool PROJ, bool NOPRO = false>   // NOPRO: ca comes from a preceding k_mlp launch
 __device__ __forceinline__ void chan_body(const FwdArgs& A, const int bid, float* smem) {
   constexpr int UN = 4;
   constexpr int HP = kProjMax;
@@ -265,7 +257,12 @@ __device__ __forceinline__ void chan_body(const FwdArgs& A, const int bid, float
       s_w1t[idx] = j < g.proj_h ? A.p.w1[static_cast<size_t>(j) * g.C + c] : 0.f;
     }
   }
-  mlp_gate_to_lds(A, b, tile == 0, s_in, s_h, s_ca);           // (its barriers also publish s_w1t)
+  if (NOPRO) {
+    for (int c = tid; c < g.C; c += kBlock) s_ca[c] = A.c.ca[static_cast<size_t>(b) * g.C + c];
+    __syncthreads();                                           // (also publishes s_w1t)
+  } else {
+    mlp_gate_to_lds(A, b, tile == 0, s_in, s_h, s_ca);         // (its barriers also publish s_w1t)
+  }
 
   float vmax[VEC], vsum[VEC];
   int vidx[VEC];
@@ -366,12 +363,12 @@ __device__ __forceinline__ void chan_body(const FwdArgs& A, const int bid, float
   }
 }
 
-template <typename T, int VEC, bool PROJ>
+template <typename T, int VEC, bool PROJ, bool NOPRO = false>
 __global__ __launch_bounds__(kBlock) void k_chan(const Group<FwdArgs> G) {
   extern __shared__ __align__(16) float smem[];
   int local;
   const int l = find_level(G, blockIdx.x, local);
-  chan_body<T, VEC, PROJ>(G.lv[l], local, smem);
+  chan_body<T, VEC, PROJ, NOPRO>(G.lv[l], local, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -738,73 +735,135 @@ __device__ __forceinline__ void gate_body(const FwdArgs& A, const int bid, float
 // tile -- as a prologue of every tile workgroup its three dependent phases cost 8.7 us per step (ablation), as the tail of
 // k_pool's last arriver 9.4 us; here it runs while the tile workgroups' x loads are in flight.
 // The MLP is a chain of dependent steps (avg/mx -> hidden -> z); fetched step by step every step pays a cross-XCD miss (the
-// operands were written by k_pool's workgroups on other XCDs, the weights are cold), ~5 latencies = 9-14 us, during which this
-// sample's tiles sit on their ca flag.  Here EVERY operand is requested up front -- avg, mx, this wave's W1 rows, this thread's W2
-// row and both biases -- so the chain costs one memory latency plus arithmetic.  The role branch shares k_gate's register
-// allocation (sized by the resident tile), so the ~40 extra registers are free.  Shapes it does not cover (C > 4*64 per wave
-// pass, hidden > kRoleH) use the staged form.
-constexpr int kRoleH = 16;      // hidden units whose W2 entries a thread keeps (C/r with r = 16: C <= 256)
-constexpr int kRoleCW = 4;      // W1 row chunks of 64 channels a lane keeps (C <= 256)
-__device__ __forceinline__ void gate_role(const FwdArgs& A, const int b, float* smem) {
+// operands were written by k_pool's workgroups on other XCDs, the weights are cold) and the loops over C and hidden serialise more
+// of them: 9-14 us at C = 64..256, 15-20 us at C = 512, during which the sample's tiles sit on their ca flag (k_gate) or every
+// workgroup of k_chan idles (prologue form).  mlp_stream requests operands in bulk instead: avg, mx and a whole pass of W1 rows
+// (up to kMlpW1 16-byte vectors per lane) are in flight together, the W2 rows are requested as soon as the W1 registers are
+// consumed, so the chain costs two memory latencies plus arithmetic.  Needs C % 4 == 0 and hidden % 4 == 0 (16-byte rows);
+// other shapes use the staged form (mlp_gate_to_lds).
+//   smem: [2C avg|mx][2h hidden]        ca is written with st_agent when `agent` (consumed inside the same launch), else plainly
+constexpr int kMlpW1 = 8;       // 16-byte vectors of W1 a lane holds per pass
+constexpr int kMlpW2 = 8;       // 16-byte vectors of W2 a thread holds per pass
+__device__ __forceinline__ bool mlp_stream_ok(const Geo& g) { return (g.C & 3) == 0 && (g.hidden & 3) == 0 && g.C <= 8 * 4 * kWave; }
+
+// hidden layer: wave w owns hidden units w, w+4, ...; a lane holds CVL vectors of each of UP rows per pass
+template <int CVL>
+__device__ __forceinline__ void mlp_hidden(const FwdArgs& A, const int b, float* s_avg, float* s_mx, float* s_h) {
+  constexpr int UP = kMlpW1 / CVL;
   const Geo& g = A.g;
-  const int tid = threadIdx.x, C = g.C, h = g.hidden;
+  const int tid = threadIdx.x, C = g.C, h = g.hidden, CV = C >> 2;
   const int wave = tid >> 6, lane = tid & 63;
-  float* s_in = smem;
-  float* s_h = smem + 2 * C;
-  float* s_ca = s_h + 2 * h;
-  int* caflag = A.c.sync + static_cast<size_t>(g.B) * A.nflag + 4 + b;
-  TRACE_MARK(A.trace, blockIdx.x, 0);
-  const bool fast = C <= kBlock && C <= kRoleCW * kWave && h <= kRoleH && h <= 4 * (kBlock / kWave);
-  if (fast) {
-    const int c = min(tid, C - 1);
-    // ---- issue everything -------------------------------------------------------------------------------------------
-    const float av = A.c.avg[static_cast<size_t>(b) * C + c], mv = A.c.mx[static_cast<size_t>(b) * C + c];
-    float w2r[kRoleH];
+  const float4* w1v = reinterpret_cast<const float4*>(A.p.w1);
+  const int nunit = h > wave ? (h - wave + 3) >> 2 : 0;        // units of this wave
+  const int npass = (((h + 3) >> 2) + UP - 1) / UP;            // uniform over the workgroup
+  for (int p = 0; p < npass; ++p) {
+    float4 wr[UP][CVL];
 #pragma unroll
-    for (int j = 0; j < kRoleH; ++j) w2r[j] = A.p.w2[static_cast<size_t>(c) * h + min(j, h - 1)];
-    const float b2c = A.p.b2[c];
-    float w1r[4][kRoleCW], b1r[4];                                // hidden units wave, wave+4, wave+8, wave+12
+    for (int uu = 0; uu < UP; ++uu) {
+      const int u = p * UP + uu, j = wave + 4 * u;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int j = min(wave + 4 * q, h - 1);
-      b1r[q] = A.p.b1[j];
-#pragma unroll
-      for (int i = 0; i < kRoleCW; ++i) w1r[q][i] = A.p.w1[static_cast<size_t>(j) * C + min(lane + kWave * i, C - 1)];
+      for (int i = 0; i < CVL; ++i) {
+        const int cv = lane + kWave * i;
+        wr[uu][i] = (u < nunit && cv < CV) ? w1v[static_cast<size_t>(j) * CV + cv] : float4{0.f, 0.f, 0.f, 0.f};
+      }
     }
-    if (tid < C) { s_in[tid] = av; s_in[C + tid] = mv; }
-    __syncthreads();
-    // ---- hidden layer: one wave per hidden unit (4 at a time) ----------------------------------------------------------------
+    if (p == 0) {                                               // the pooled descriptors, requested right behind the first W1 rows
+      for (int c = tid; c < C; c += kBlock) {
+        s_avg[c] = A.c.avg[static_cast<size_t>(b) * C + c];
+        s_mx[c] = A.c.mx[static_cast<size_t>(b) * C + c];
+      }
+      __syncthreads();
+    }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int j = wave + 4 * q;
-      if (j < h) {                                                // (uniform per wave)
+    for (int uu = 0; uu < UP; ++uu) {
+      const int u = p * UP + uu;
+      if (u < nunit) {                                          // (uniform per wave)
         float da = 0.f, dm = 0.f;
 #pragma unroll
-        for (int i = 0; i < kRoleCW; ++i) {
-          const int cc = lane + kWave * i;
-          if (cc < C) { da += w1r[q][i] * s_in[cc]; dm += w1r[q][i] * s_in[C + cc]; }
+        for (int i = 0; i < CVL; ++i) {
+          const int cv = lane + kWave * i;
+          if (cv < CV) {
+            const float4 w = wr[uu][i];
+            const float4 a4 = *reinterpret_cast<const float4*>(s_avg + 4 * cv), m4 = *reinterpret_cast<const float4*>(s_mx + 4 * cv);
+            da += w.x * a4.x + w.y * a4.y + w.z * a4.z + w.w * a4.w;
+            dm += w.x * m4.x + w.y * m4.y + w.z * m4.z + w.w * m4.w;
+          }
         }
         da = wave_group_sum(da, kWave);
         dm = wave_group_sum(dm, kWave);
         if (lane == 0) {
-          const float ha = fmaxf(da + b1r[q], 0.f), hm = fmaxf(dm + b1r[q], 0.f);
+          const int j = wave + 4 * u;
+          const float bj = A.p.b1[j];
+          const float ha = fmaxf(da + bj, 0.f), hm = fmaxf(dm + bj, 0.f);
           s_h[j] = ha; s_h[h + j] = hm;
           A.c.h_avg[static_cast<size_t>(b) * h + j] = ha;
           A.c.h_mx[static_cast<size_t>(b) * h + j] = hm;
         }
       }
     }
-    __syncthreads();
-    TRACE_MARK(A.trace, blockIdx.x, 3);
-    if (tid < C) {
-      float za = 0.f, zm = 0.f;
+  }
+}
+
+template <bool AGENT>
+__device__ __forceinline__ void mlp_stream(const FwdArgs& A, const int b, float* smem) {
+  const Geo& g = A.g;
+  const int tid = threadIdx.x, C = g.C, h = g.hidden;
+  float* s_avg = smem;
+  float* s_mx = smem + C;
+  float* s_h = smem + 2 * C;
+  const int cvl = ((C >> 2) + kWave - 1) / kWave;              // vectors of a W1 row per lane: 1 (C <= 256), 2, 4, 8 (C <= 2048)
+  if (cvl <= 1) mlp_hidden<1>(A, b, s_avg, s_mx, s_h);
+  else if (cvl <= 2) mlp_hidden<2>(A, b, s_avg, s_mx, s_h);
+  else if (cvl <= 4) mlp_hidden<4>(A, b, s_avg, s_mx, s_h);
+  else mlp_hidden<8>(A, b, s_avg, s_mx, s_h);
+  // ---- output layer: thread = channel; its first W2 row is requested BEFORE the barrier that publishes the hidden activations -------
+  const int HV = h >> 2;
+  const float4* w2v = reinterpret_cast<const float4*>(A.p.w2);
+  float4 wr[kMlpW2];
+  {
+    const int c = min(tid, C - 1);
 #pragma unroll
-      for (int j = 0; j < kRoleH; ++j)
-        if (j < h) { za += w2r[j] * s_h[j]; zm += w2r[j] * s_h[h + j]; }
-      const float z = (za + b2c) + (zm + b2c);                    // same association as mlp_gate_to_lds
-      st_agent(A.c.ca + static_cast<size_t>(b) * C + tid, sigmoidf_(z));
+    for (int q = 0; q < kMlpW2; ++q) wr[q] = q < HV ? w2v[static_cast<size_t>(c) * HV + q] : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += kBlock) {
+    float za = 0.f, zm = 0.f;
+    for (int v0 = 0; v0 < HV; v0 += kMlpW2) {
+      if (c != tid || v0 != 0) {
+#pragma unroll
+        for (int q = 0; q < kMlpW2; ++q) wr[q] = v0 + q < HV ? w2v[static_cast<size_t>(c) * HV + v0 + q] : float4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int q = 0; q < kMlpW2; ++q) {
+        if (v0 + q < HV) {
+          const float* ha = s_h + 4 * (v0 + q);
+          const float* hm = ha + h;
+          za += wr[q].x * ha[0]; zm += wr[q].x * hm[0];          // j ascending: the summation order of mlp_gate_to_lds
+          za += wr[q].y * ha[1]; zm += wr[q].y * hm[1];
+          za += wr[q].z * ha[2]; zm += wr[q].z * hm[2];
+          za += wr[q].w * ha[3]; zm += wr[q].w * hm[3];
+        }
+      }
     }
+    const float bc = A.p.b2[c];
+    const float ca = sigmoidf_((za + bc) + (zm + bc));
+    if (AGENT) st_agent(A.c.ca + static_cast<size_t>(b) * C + c, ca);
+    else A.c.ca[static_cast<size_t>(b) * C + c] = ca;
+  }
+}
+
+__device__ __forceinline__ void gate_role(const FwdArgs& A, const int b, float* smem) {
+  const Geo& g = A.g;
+  const int tid = threadIdx.x, C = g.C, h = g.hidden;
+  int* caflag = A.c.sync + static_cast<size_t>(g.B) * A.nflag + 4 + b;
+  TRACE_MARK(A.trace, blockIdx.x, 0);
+  if (mlp_stream_ok(g)) {
+    mlp_stream<true>(A, b, smem);
+    TRACE_MARK(A.trace, blockIdx.x, 3);
   } else {
+    float* s_in = smem;
+    float* s_h = smem + 2 * C;
+    float* s_ca = s_h + 2 * h;
     mlp_gate_to_lds(A, b, false, s_in, s_h, s_ca);
     TRACE_MARK(A.trace, blockIdx.x, 3);
     for (int c = tid; c < C; c += kBlock) st_agent(A.c.ca + static_cast<size_t>(b) * C + c, s_ca[c]);
@@ -815,6 +874,22 @@ __device__ __forceinline__ void gate_role(const FwdArgs& A, const int b, float* 
   }
   if (!(A.fault && b == 0)) handoff_publish(caflag);           // (fault injection, tests only: sample 0's tiles time out)
   TRACE_MARK(A.trace, blockIdx.x, 5);
+}
+
+// k_mlp: the shared MLP + channel gate as a launch of its own, one workgroup per sample (levels concatenated).  Used in front of
+// k_chan when the prologue form would cost more than a launch: with C*hidden large every one of k_chan's ~2000 workgroups spends
+// 15-20 us in the MLP before it streams (config 4: k_chan 98 us against 53 us of traffic).
+__global__ __launch_bounds__(kBlock) void k_mlp(const Group<FwdArgs> G) {
+  extern __shared__ __align__(16) float smem[];
+  int local;
+  const int l = find_level(G, blockIdx.x, local);
+  const FwdArgs& A = G.lv[l];
+  if (mlp_stream_ok(A.g)) {
+    mlp_stream<false>(A, local, smem);
+  } else {
+    float* s_h = smem + 2 * A.g.C;
+    mlp_gate_to_lds(A, local, true, smem, s_h, s_h + 2 * A.g.hidden);
+  }
 }
 
 struct GateGroup {

@@ -21,6 +21,7 @@
 #include "eca.cuh"
 #include "segloss.cuh"
 #include "gater.cuh"
+#include "head.cuh"
 #include "fwd.cuh"
 
 using namespace mgacbam;
@@ -118,7 +119,7 @@ static int env_int(const char* name, int dflt) {
 // Tuning / test knobs come from the environment ONCE (first call) -- not per call: the eager path makes ~50 look-ups per step
 // otherwise.  mgacbam_reload_env() re-reads them (tests and tuning sweeps that change the environment in-process).
 struct Knobs {
-  int gate, chan_mintx, pool_tx, pool_cpt, chan_tx, chanf_tx, nt, half_vec, gate_h8, level_order, bwd_fold, pool_rot;
+  int gate, chan_mintx, pool_tx, pool_cpt, chan_tx, chanf_tx, split_mlp, nt, half_vec, gate_h8, level_order, bwd_fold;
   int resident_wgs;        // MGACBAM_RESIDENT_WGS: override of the co-resident workgroup budget the hand-off eligibility is sized from
   int fault;               // MGACBAM_FAULT: fault injection for tests (args.cuh)
   unsigned spin_limit;     // MGACBAM_SPIN_LIMIT
@@ -130,7 +131,7 @@ static Knobs read_knobs() {
   k.pool_tx = env_int("MGACBAM_POOL_TX", 0); k.pool_cpt = env_int("MGACBAM_POOL_CPT", 0); k.chan_tx = env_int("MGACBAM_CHAN_TX", 0);
   k.nt = env_int("MGACBAM_NT", 1); k.half_vec = env_int("MGACBAM_HALF_VEC", 4); k.gate_h8 = env_int("MGACBAM_GATE_H8", 1);
   k.level_order = env_int("MGACBAM_LEVEL_ORDER", 1); k.bwd_fold = env_int("MGACBAM_BWD_FOLD", 1);
-  k.pool_rot = env_int("MGACBAM_POOL_ROT", 1); k.chanf_tx = env_int("MGACBAM_CHANF_TX", 0);
+  k.chanf_tx = env_int("MGACBAM_CHANF_TX", 0); k.split_mlp = env_int("MGACBAM_SPLIT_MLP", -1);
   k.resident_wgs = env_int("MGACBAM_RESIDENT_WGS", 0); k.fault = env_int("MGACBAM_FAULT", 0);
   const int sl = env_int("MGACBAM_SPIN_LIMIT", 0);
   k.spin_limit = sl > 0 ? static_cast<unsigned>(sl) : (1u << 20);
@@ -232,7 +233,7 @@ static Tune choose_tune(int B, int C, int H, int W, int k, int dtype = MGACBAM_F
   if (tx > 256) tx = 256;
   int cpt = 4;
   while (cpt > 1 && static_cast<long long>(B) * ((C + (256 / tx) * cpt - 1) / ((256 / tx) * cpt)) < 1024) cpt /= 2;
-  t.pool_tx = tx; t.pool_cpt = cpt; t.pool_rot = kn.pool_rot ? 1 : 0;
+  t.pool_tx = tx; t.pool_cpt = cpt;
   // one H*W vector per lane, TY channel slices: TX <= 64 so row reductions are pure wave shuffles
   int ctx = pow2_ceil(nv) < 64 ? pow2_ceil(nv) : 64;
   const int min_tx = kn.chan_mintx;
@@ -407,7 +408,7 @@ static size_t apply_smem(const Geo& g, const Tune& t, int vec) {
 }
 static size_t gate_smem(const Geo& g, const Tune& t, int vec) {
   const size_t head = (g.C + 3) & ~3;
-  const size_t role = 3 * static_cast<size_t>(g.C) + 2 * g.hidden;           // gate_role: the MLP's scratch
+  const size_t role = 3 * static_cast<size_t>(g.C) + 2 * g.hidden;           // gate_role: the MLP's scratch (staged form: [2C][2h][C])
   const size_t conv = ((3 * g.k * g.k + 3) & ~3) + 3 * static_cast<size_t>(t.gate_rows) * (g.W + g.k - 1) + static_cast<size_t>(t.gate_tx) * vec;
   return std::max(role, head + std::max(conv, static_cast<size_t>(3) * kBlock * vec)) * sizeof(float);
 }
@@ -505,11 +506,24 @@ static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStre
 #undef CALL_GATE
     return launch_status("k_gate");
   }
-  if (stages & MGACBAM_FWD_CHAN) {  // 2. shared MLP + channel gate (prologue), channel max / mean planes
+  if (stages & MGACBAM_FWD_CHAN) {  // 2. shared MLP + channel gate (prologue, or a launch of its own), channel max / mean planes
+    // With C*hidden large the MLP prologue keeps every k_chan workgroup from streaming for 15-20 us; one tiny launch per step is cheaper
+    bool split_mlp = false;
+    for (int l = 0; l < n; ++l) split_mlp |= static_cast<long long>(lv[l].g.C) * lv[l].g.hidden >= 8192;
+    { const int f = knobs().split_mlp; if (f == 0) split_mlp = false; else if (f == 1) split_mlp = true; }
+    if (split_mlp) {
+      size_t msmem = 0;
+      for (int l = 0; l < n; ++l) msmem = std::max(msmem, (3 * static_cast<size_t>(lv[l].g.C) + 2 * lv[l].g.hidden) * sizeof(float));
+      const int mgrid = fill([&](const FwdArgs& a) { return a.g.B; });
+      LAUNCH(k_mlp, mgrid, msmem, st, G);
+      if (int e = launch_status("k_mlp")) return e;
+    }
     size_t smem = 0;
     for (int l = 0; l < n; ++l) smem = std::max(smem, chan_smem(lv[l].g, sig.vec, sig.proj));
     const int grid = fill([&](const FwdArgs& a) { return xcd_grid(a.g.B, (a.g.HW / sig.vec + a.t.chanf_tx - 1) / a.t.chanf_tx); });
-#define CALL_CHAN(Tt, Vv) if (sig.proj) LAUNCH((k_chan<Tt, Vv, true>), grid, smem, st, G); else LAUNCH((k_chan<Tt, Vv, false>), grid, smem, st, G)
+#define CALL_CHAN(Tt, Vv)                                                                                         \
+    if (split_mlp) { if (sig.proj) LAUNCH((k_chan<Tt, Vv, true, true>), grid, smem, st, G); else LAUNCH((k_chan<Tt, Vv, false, true>), grid, smem, st, G); } \
+    else { if (sig.proj) LAUNCH((k_chan<Tt, Vv, true>), grid, smem, st, G); else LAUNCH((k_chan<Tt, Vv, false>), grid, smem, st, G); }
     DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_CHAN);
 #undef CALL_CHAN
     if (int e = launch_status("k_chan")) return e;
@@ -532,6 +546,10 @@ static int forward_group(FwdArgs* lv, int n, const Sig& sig, int stages, hipStre
   return 0;
 }
 
+// ~ how long a workgroup of the level runs (channels per thread of the tile kernels); levels are launched longest first
+template <typename A> static auto level_weight(const A& a, int) -> decltype(a.t.chan_tx, 0) { return a.g.C * a.t.chan_tx; }
+template <typename A> static int level_weight(const A& a, long) { return a.g.C; }
+
 // partition the levels into launch groups (same signature, at most kGroupMax levels) and run `run` on each
 template <typename Args, typename Run>
 static int for_each_group(Args* args, const Sig* sigs, int n, Run run) {
@@ -544,8 +562,7 @@ static int for_each_group(Args* args, const Sig* sigs, int n, Run run) {
       if (!done[j] && sigs[j] == sigs[l]) { grp[m++] = args[j]; done[j] = true; }
     if (knobs().level_order)
       std::stable_sort(grp, grp + m, [](const Args& a, const Args& b) {
-        const int ca = a.g.C * a.t.chan_tx, cb = b.g.C * b.t.chan_tx;   // ~ channels per thread of the tile kernels
-        return ca > cb;
+        return level_weight(a, 0) > level_weight(b, 0);
       });
     if (int e = run(grp, m, sigs[l])) return e;
   }
@@ -980,6 +997,226 @@ extern "C" int mgaseg_backward(const mgaseg_level_t* levels, int n, const mgaseg
     default: LAUNCH(k_seg_bwd<bf16_t>, grid, 0, st, A); break;
   }
   if (int e = launch_status("k_seg_bwd")) return e;
+  g_err[0] = 0;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MGAMaskHead
+// ------------------------------------------------------------------------------------------------
+static int head_check_shape(int B, int C, int H, int W, int hidden) {
+  if (B < 1 || C < 1 || H < 1 || W < 1 || hidden < 1 || hidden > 1024 || C > 8192)
+    return fail(MGACBAM_E_SHAPE, "mask head: bad shape B=%d C=%d H=%d W=%d hidden=%d", B, C, H, W, hidden);
+  if (static_cast<long long>(H) * W > (1ll << 28) || static_cast<long long>(B) * std::max(C, hidden) * H * W > (1ll << 40))
+    return fail(MGACBAM_E_SHAPE, "mask head: tensor too large B=%d C=%d H=%d W=%d", B, C, H, W);
+  return 0;
+}
+struct HeadTiling { int vec, hidp, cp, tile_px, tps, nwg, gx_tile_px, gx_tps, t2x, t2y, nwg1, ncb; };
+static int head_pw(int mtiles) {                                 // waves along pixels of k_head_gemm for `mtiles` 16-output tiles (head.cuh)
+  int mw = std::min(4, (mtiles + kHeadMTW - 1) / kHeadMTW);
+  if (mw == 3) mw = 4;
+  return 4 / mw;
+}
+static HeadTiling head_tiling(int B, int C, int H, int W, int hidden) {
+  HeadTiling t;
+  const int HW = H * W;
+  t.vec = (HW % 4 == 0) ? 4 : 1;
+  t.hidp = (hidden + 15) & ~15; t.cp = (C + 15) & ~15;
+  t.tile_px = head_pw(t.hidp / 16) * 16 * t.vec;
+  t.tps = (HW + t.tile_px - 1) / t.tile_px;
+  t.nwg = B * t.tps;
+  t.gx_tile_px = head_pw(t.cp / 16) * 16 * t.vec;
+  t.gx_tps = (HW + t.gx_tile_px - 1) / t.gx_tile_px;
+  t.t2x = (W + kHeadT2 - 1) / kHeadT2; t.t2y = (H + kHeadT2 - 1) / kHeadT2;
+  t.nwg1 = B * t.t2x * t.t2y;
+  t.ncb = (C + kHeadCB - 1) / kHeadCB;
+  return t;
+}
+struct HeadCtxLayout { size_t z, mean, rstd, part, total; };
+static HeadCtxLayout head_ctx_layout(int B, int C, int H, int W, int hidden) {
+  const HeadTiling t = head_tiling(B, C, H, W, hidden);
+  HeadCtxLayout L;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t at = o; o = align16(o + n * 4); return at; };
+  L.z = take(static_cast<size_t>(B) * hidden * H * W);
+  L.mean = take(t.hidp); L.rstd = take(t.hidp);
+  L.part = take(static_cast<size_t>(t.nwg) * 2 * t.hidp);
+  L.total = o;
+  return L;
+}
+struct HeadScratchLayout { size_t ga, part1, kst, gwpart, total; };
+static HeadScratchLayout head_scratch_layout(int B, int C, int H, int W, int hidden) {
+  const HeadTiling t = head_tiling(B, C, H, W, hidden);
+  HeadScratchLayout L;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t at = o; o = align16(o + n * 4); return at; };
+  L.ga = take(static_cast<size_t>(B) * hidden * H * W);
+  L.part1 = take(static_cast<size_t>(t.nwg1) * t.hidp * kHeadNStat);
+  L.kst = take(5 * static_cast<size_t>(t.hidp));
+  L.gwpart = take(static_cast<size_t>(t.ncb) * kHeadGwWG * t.hidp * kHeadCB);
+  L.total = o;
+  return L;
+}
+extern "C" size_t mgahead_ctx_bytes(int B, int C, int H, int W, int hidden) {
+  if (head_check_shape(B, C, H, W, hidden)) return 0;
+  return head_ctx_layout(B, C, H, W, hidden).total;
+}
+extern "C" size_t mgahead_bwd_scratch_bytes(int B, int C, int H, int W, int hidden) {
+  if (head_check_shape(B, C, H, W, hidden)) return 0;
+  return head_scratch_layout(B, C, H, W, hidden).total;
+}
+static int head_common(const mgahead_params_t& P, int B, int C, int H, int W, int dtype, void* ctx, HeadArgs& A, Sig& sig) {
+  if (!P.w1 || !P.bn_weight || !P.bn_bias || !P.running_mean || !P.running_var || !P.wh || !P.bh)
+    return fail(MGACBAM_E_NULL, "mask head: NULL parameter pointer");
+  if (int e = head_check_shape(B, C, H, W, P.hidden)) return e;
+  if (dtype < MGACBAM_F32 || dtype > MGACBAM_BF16) return fail(MGACBAM_E_DTYPE, "mask head: dtype %d", dtype);
+  if (!(P.eps > 0.f) || !(P.momentum >= 0.f && P.momentum <= 1.f)) return fail(MGACBAM_E_SHAPE, "mask head: eps=%g momentum=%g", P.eps, P.momentum);
+  const HeadTiling t = head_tiling(B, C, H, W, P.hidden);
+  memset(&A, 0, sizeof(A));
+  A.p = HeadPtrs{P.w1, P.bn_weight, P.bn_bias, P.running_mean, P.running_var, reinterpret_cast<long long*>(P.num_batches_tracked), P.wh, P.bh};
+  A.g.B = B; A.g.C = C; A.g.hid = P.hidden; A.g.H = H; A.g.W = W; A.g.HW = H * W; A.g.hidp = t.hidp; A.g.cp = t.cp;
+  A.g.eps = P.eps; A.g.momentum = P.momentum; A.g.training = P.training ? 1 : 0;
+  const HeadCtxLayout L = head_ctx_layout(B, C, H, W, P.hidden);
+  char* cp = static_cast<char*>(ctx);
+  A.c = HeadCtx{reinterpret_cast<float*>(cp + L.z), reinterpret_cast<float*>(cp + L.mean), reinterpret_cast<float*>(cp + L.rstd),
+                reinterpret_cast<float*>(cp + L.part)};
+  A.tile_px = t.tile_px; A.tiles_per_sample = t.tps; A.nwg = t.nwg;
+  A.gx_tile_px = t.gx_tile_px; A.gx_tiles_per_sample = t.gx_tps;
+  A.t2x = t.t2x; A.t2y = t.t2y; A.nwg1 = t.nwg1; A.ncb = t.ncb;
+  sig = Sig{dtype, t.vec, 0, 0, 0, 0};
+  return 0;
+}
+static size_t head_gemm_smem(const HeadArgs* lv, int n) {
+  size_t m = 0;
+  for (int l = 0; l < n; ++l) m = std::max(m, (static_cast<size_t>(kHeadLdsA) + 8 * lv[l].g.hidp) * sizeof(float));
+  return m;
+}
+template <typename Fn>
+static int head_fill(Group<HeadArgs>& G, const HeadArgs* lv, int n, Fn blocks_of) {
+  int tot = 0;
+  for (int l = 0; l < n; ++l) { G.start[l] = tot; tot += blocks_of(lv[l]); }
+  G.start[n] = tot;
+  return tot;
+}
+static int head_forward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t st) {
+  Group<HeadArgs> G;
+  G.n = n;
+  for (int l = 0; l < n; ++l) G.lv[l] = lv[l];
+  {
+    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.nwg; });
+    const size_t smem = head_gemm_smem(lv, n);
+#define CALL_HP(Tt, Vv) LAUNCH((k_head_gemm<Tt, Vv, false>), grid, smem, st, G)
+    if (sig.dtype == MGACBAM_F32) { if (sig.vec == 4) { CALL_HP(float, 4); } else { CALL_HP(float, 1); } }
+    else if (sig.dtype == MGACBAM_F16) { if (sig.vec == 4) { CALL_HP(__half, 4); } else { CALL_HP(__half, 1); } }
+    else { if (sig.vec == 4) { CALL_HP(bf16_t, 4); } else { CALL_HP(bf16_t, 1); } }
+#undef CALL_HP
+    if (int e = launch_status("k_head_gemm<fwd>")) return e;
+  }
+  {
+    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return (a.g.hid + 7) / 8; });
+    LAUNCH(k_head_stats, grid, 0, st, G);
+    if (int e = launch_status("k_head_stats")) return e;
+  }
+  {
+    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.nwg1; });
+    const size_t smem = (static_cast<size_t>(kHeadJC) * (kHeadT2 + 2) * (kHeadT2 + 2) + kHeadJC * 11) * sizeof(float);
+    switch (sig.dtype) {
+      case MGACBAM_F32: LAUNCH(k_head_out<float>, grid, smem, st, G); break;
+      case MGACBAM_F16: LAUNCH(k_head_out<__half>, grid, smem, st, G); break;
+      default: LAUNCH(k_head_out<bf16_t>, grid, smem, st, G); break;
+    }
+    if (int e = launch_status("k_head_out")) return e;
+  }
+  return 0;
+}
+extern "C" int mgahead_forward(const mgahead_fwd_level_t* levels, int n_levels, void* stream) {
+  if (!levels) return fail(MGACBAM_E_NULL, "levels is NULL");
+  if (n_levels < 1 || n_levels > MGACBAM_MAX_LEVELS) return fail(MGACBAM_E_LEVELS, "n_levels=%d", n_levels);
+  HeadArgs args[MGACBAM_MAX_LEVELS];
+  Sig sigs[MGACBAM_MAX_LEVELS];
+  for (int l = 0; l < n_levels; ++l) {
+    const mgahead_fwd_level_t& L = levels[l];
+    if (!L.x || !L.logits || !L.ctx) return fail(MGACBAM_E_NULL, "mask head forward: x / logits / ctx is NULL");
+    if (int e = head_common(L.p, L.B, L.C, L.H, L.W, L.dtype, L.ctx, args[l], sigs[l])) return e;
+    const size_t need = sigs[l].vec * elem_size(L.dtype);
+    if (!aligned_to(L.x, need) || !aligned_to(L.ctx, 16)) return fail(MGACBAM_E_ALIGN, "mask head forward: x must be %zu-byte aligned, ctx 16-byte", need);
+    args[l].x = L.x; args[l].logits = L.logits;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (int e = for_each_group(args, sigs, n_levels, [&](HeadArgs* g, int m, const Sig& s) { return head_forward_group(g, m, s, st); })) return e;
+  g_err[0] = 0;
+  return 0;
+}
+static int head_backward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t st) {
+  Group<HeadArgs> G;
+  G.n = n;
+  for (int l = 0; l < n; ++l) G.lv[l] = lv[l];
+  {
+    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.nwg1; });
+    const size_t smem = (static_cast<size_t>(kHeadT2 + 2) * (kHeadT2 + 2) + 4 * kHeadJC * kHeadNStat) * sizeof(float);
+    switch (sig.dtype) {
+      case MGACBAM_F32: LAUNCH(k_head_bwd_act<float>, grid, smem, st, G); break;
+      case MGACBAM_F16: LAUNCH(k_head_bwd_act<__half>, grid, smem, st, G); break;
+      default: LAUNCH(k_head_bwd_act<bf16_t>, grid, smem, st, G); break;
+    }
+    if (int e = launch_status("k_head_bwd_act")) return e;
+  }
+  {
+    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.g.hid; });
+    LAUNCH(k_head_bwd_fin, grid, 0, st, G);
+    if (int e = launch_status("k_head_bwd_fin")) return e;
+  }
+  {
+    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.g.B * a.gx_tiles_per_sample; });
+    const size_t smem = head_gemm_smem(lv, n);
+#define CALL_HX(Tt, Vv) LAUNCH((k_head_gemm<Tt, Vv, true>), grid, smem, st, G)
+    if (sig.dtype == MGACBAM_F32) { if (sig.vec == 4) { CALL_HX(float, 4); } else { CALL_HX(float, 1); } }
+    else if (sig.dtype == MGACBAM_F16) { if (sig.vec == 4) { CALL_HX(__half, 4); } else { CALL_HX(__half, 1); } }
+    else { if (sig.vec == 4) { CALL_HX(bf16_t, 4); } else { CALL_HX(bf16_t, 1); } }
+#undef CALL_HX
+    if (int e = launch_status("k_head_gemm<gx>")) return e;
+  }
+  {
+    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.ncb * kHeadGwWG; });
+    size_t smem = 0;
+    for (int l = 0; l < n; ++l) smem = std::max(smem, (5 * static_cast<size_t>(lv[l].g.hidp) + 1024) * sizeof(float));
+#define CALL_HW(Tt, Vv) LAUNCH((k_head_bwd_gw<Tt, Vv>), grid, smem, st, G)
+    if (sig.dtype == MGACBAM_F32) { if (sig.vec == 4) { CALL_HW(float, 4); } else { CALL_HW(float, 1); } }
+    else if (sig.dtype == MGACBAM_F16) { if (sig.vec == 4) { CALL_HW(__half, 4); } else { CALL_HW(__half, 1); } }
+    else { if (sig.vec == 4) { CALL_HW(bf16_t, 4); } else { CALL_HW(bf16_t, 1); } }
+#undef CALL_HW
+    if (int e = launch_status("k_head_bwd_gw")) return e;
+  }
+  {
+    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return (a.g.hid * a.g.C + kBlock - 1) / kBlock; });
+    LAUNCH(k_head_bwd_gwf, grid, 0, st, G);
+    if (int e = launch_status("k_head_bwd_gwf")) return e;
+  }
+  return 0;
+}
+extern "C" int mgahead_backward(const mgahead_bwd_level_t* levels, int n_levels, void* stream) {
+  if (!levels) return fail(MGACBAM_E_NULL, "levels is NULL");
+  if (n_levels < 1 || n_levels > MGACBAM_MAX_LEVELS) return fail(MGACBAM_E_LEVELS, "n_levels=%d", n_levels);
+  HeadArgs args[MGACBAM_MAX_LEVELS];
+  Sig sigs[MGACBAM_MAX_LEVELS];
+  for (int l = 0; l < n_levels; ++l) {
+    const mgahead_bwd_level_t& L = levels[l];
+    if (!L.x || !L.g_logits || !L.ctx || !L.scratch || !L.gx) return fail(MGACBAM_E_NULL, "mask head backward: x / g_logits / ctx / scratch / gx is NULL");
+    if (!L.gw1 || !L.gbn_weight || !L.gbn_bias || !L.gwh || !L.gbh) return fail(MGACBAM_E_NULL, "mask head backward: NULL parameter-gradient pointer");
+    if (int e = head_common(L.p, L.B, L.C, L.H, L.W, L.dtype, const_cast<void*>(L.ctx), args[l], sigs[l])) return e;
+    const size_t need = sigs[l].vec * elem_size(L.dtype);
+    if (!aligned_to(L.x, need) || !aligned_to(L.gx, need) || !aligned_to(L.ctx, 16) || !aligned_to(L.scratch, 16))
+      return fail(MGACBAM_E_ALIGN, "mask head backward: x/gx must be %zu-byte aligned, ctx/scratch 16-byte", need);
+    HeadArgs& A = args[l];
+    A.x = L.x; A.gl = L.g_logits; A.gx = L.gx;
+    A.gw1 = L.gw1; A.ggamma = L.gbn_weight; A.gbeta = L.gbn_bias; A.gwh = L.gwh; A.gbh = L.gbh;
+    const HeadScratchLayout SL = head_scratch_layout(L.B, L.C, L.H, L.W, L.p.hidden);
+    char* sp = static_cast<char*>(L.scratch);
+    A.s = HeadScratch{reinterpret_cast<float*>(sp + SL.ga), reinterpret_cast<float*>(sp + SL.part1), reinterpret_cast<float*>(sp + SL.kst),
+                      reinterpret_cast<float*>(sp + SL.gwpart)};
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (int e = for_each_group(args, sigs, n_levels, [&](HeadArgs* g, int m, const Sig& s) { return head_backward_group(g, m, s, st); })) return e;
   g_err[0] = 0;
   return 0;
 }

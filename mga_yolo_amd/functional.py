@@ -485,3 +485,103 @@ def prob_mask_gate(p: torch.Tensor, u1: torch.Tensor, u2: torch.Tensor, tau: flo
     """Gumbel-sigmoid gate of ProbMaskGater for device tensors: max(clamp(p,0,1), p_min) -> sigmoid((logit + logistic(u1,u2)) / tau),
     thresholded with a straight-through gradient when ``hard``.  u1, u2: uniform draws, as torch.rand gives them."""
     return _GaterFn.apply(p, u1, u2, tau, p_min, threshold, hard)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# MGAMaskHead (SURVEY 8f-1): Conv1x1 -> BatchNorm2d -> SiLU -> Conv3x3 as 3 launches forward, 5 backward (csrc/head.cuh)
+# ---------------------------------------------------------------------------------------------------------
+def _head_params(w1, gamma, beta, rmean, rvar, nbt, wh, bh, hidden, eps, momentum, training) -> "_lib.HeadParams":
+    return _lib.HeadParams(w1.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
+                           None if nbt is None else nbt.data_ptr(), wh.data_ptr(), bh.data_ptr(), hidden, eps, momentum, int(training))
+
+
+class _HeadFn(torch.autograd.Function):
+    """n independent levels; flat inputs = n x (x, proj.0.weight, proj.1.weight, proj.1.bias, head.weight, head.bias);
+    ``state`` = per level (running_mean, running_var, num_batches_tracked | None, eps, momentum, training): buffers updated in place."""
+
+    @staticmethod
+    def forward(ctx, state: tuple, *flat):
+        n = len(state)
+        assert len(flat) == 6 * n and 1 <= n <= _lib.MAX_LEVELS
+        lib = _lib.load()
+        levels = (_lib.HeadFwdLevel * n)()
+        keep, outs, meta = [], [], []
+        dev = flat[0].device
+        if not flat[0].is_cuda:
+            raise RuntimeError("mask_head: device tensors only (host tensors take the module's host path)")
+        for l in range(n):
+            x, w1, gamma, beta, wh, bh = flat[6 * l:6 * l + 6]
+            rmean, rvar, nbt, eps, momentum, training = state[l]
+            if x.dim() != 4 or x.dtype not in _DTYPES or x.device != dev:
+                raise RuntimeError("mask_head: x must be a (B,C,H,W) fp32 / fp16 / bf16 tensor on one GPU")
+            B, Cc, H, W = x.shape
+            hid = w1.shape[0]
+            if tuple(w1.shape[:2]) != (hid, Cc) or tuple(wh.shape) != (1, hid, 3, 3) or bh.numel() != 1 or gamma.numel() != hid:
+                raise ValueError(f"mask_head: parameter shapes do not match C={Cc}, hidden={hid} (out_channels must be 1)")
+            xc = _ready(x)
+            pc = [_ready(t.float() if t.dtype != torch.float32 else t) for t in (w1, gamma, beta, wh, bh)]
+            for t in (rmean, rvar):
+                if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+                    raise ValueError("mask_head: running statistics must be contiguous fp32 tensors on the feature's device")
+            logits = torch.empty(B, 1, H, W, dtype=x.dtype, device=dev)
+            cbuf = torch.empty(lib.mgahead_ctx_bytes(B, Cc, H, W, hid), dtype=torch.uint8, device=dev)
+            L = levels[l]
+            L.x, L.logits, L.ctx = xc.data_ptr(), logits.data_ptr(), cbuf.data_ptr()
+            L.p = _head_params(*pc[:3], rmean, rvar, nbt, *pc[3:], hid, float(eps), float(momentum), training)
+            L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[x.dtype]
+            keep += [xc, cbuf, *pc, rmean, rvar]
+            outs.append(logits)
+            meta.append((hid, float(eps), float(momentum), bool(training), tuple(w1.shape)))
+        with torch.cuda.device(dev):
+            _lib.check(lib.mgahead_forward(levels, n, torch.cuda.current_stream(dev).cuda_stream), "mgahead_forward")
+        ctx.save_for_backward(*keep)
+        ctx.meta = meta
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gls):
+        n = len(ctx.meta)
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        levels = (_lib.HeadBwdLevel * n)()
+        grads: List[Optional[torch.Tensor]] = [None]
+        hold = []
+        dev = saved[0].device
+        for l in range(n):
+            xc, cbuf, w1, gamma, beta, wh, bh, rmean, rvar = saved[9 * l:9 * l + 9]
+            hid, eps, momentum, training, w1_shape = ctx.meta[l]
+            B, Cc, H, W = xc.shape
+            gl = gls[l]
+            gl = torch.zeros(B, 1, H, W, dtype=xc.dtype, device=dev) if gl is None else _aligned(gl.to(xc.dtype))
+            gx = torch.empty_like(xc)
+            pg = [torch.empty_like(t) for t in (w1, gamma, beta, wh, bh)]
+            scratch = torch.empty(lib.mgahead_bwd_scratch_bytes(B, Cc, H, W, hid), dtype=torch.uint8, device=dev)
+            L = levels[l]
+            L.x, L.g_logits, L.ctx, L.scratch, L.gx = xc.data_ptr(), gl.data_ptr(), cbuf.data_ptr(), scratch.data_ptr(), gx.data_ptr()
+            L.gw1, L.gbn_weight, L.gbn_bias, L.gwh, L.gbh = (t.data_ptr() for t in pg)
+            L.p = _head_params(w1, gamma, beta, rmean, rvar, None, wh, bh, hid, eps, momentum, training)
+            L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[xc.dtype]
+            hold += [gl, scratch]
+            pg[0] = pg[0].view(w1_shape)
+            grads += [gx, *pg]
+        with torch.cuda.device(dev):
+            _lib.check(lib.mgahead_backward(levels, n, torch.cuda.current_stream(dev).cuda_stream), "mgahead_backward")
+        del hold
+        return tuple(grads)
+
+
+def mask_head(x: torch.Tensor, w1, bn_weight, bn_bias, running_mean, running_var, num_batches_tracked, wh, bh,
+              eps: float = 1e-5, momentum: float = 0.1, training: bool = True) -> torch.Tensor:
+    """Mask logits (B,1,H,W) = Conv3x3(SiLU(BatchNorm2d(Conv1x1(x)))) for a device tensor x; in training the running statistics
+    (and num_batches_tracked) are updated in place exactly as torch's BatchNorm2d does (mga_yolo/nn/modules/segmentation.py:56-110)."""
+    return _HeadFn.apply(((running_mean, running_var, num_batches_tracked, eps, momentum, training),), x, w1, bn_weight, bn_bias, wh, bh)[0]
+
+
+def mask_head_pyramid(levels):
+    """levels: [(x, w1, bn_weight, bn_bias, running_mean, running_var, num_batches_tracked, wh, bh, eps, momentum, training), ...]
+    -> tuple of logits; ONE library call each way for all levels (the three heads read different features: they are independent)."""
+    state, flat = [], []
+    for x, w1, g_, b_, rm, rv, nbt, wh, bh, eps, mom, tr in levels:
+        state.append((rm, rv, nbt, eps, mom, tr))
+        flat += [x, w1, g_, b_, wh, bh]
+    return _HeadFn.apply(tuple(state), *flat)

@@ -17,16 +17,17 @@ import importlib
 import sys
 from typing import Dict, List
 
-from .module import MaskCBAM, MaskECA
+from .module import MGAMaskHead, MaskCBAM, MaskECA
 from .segloss import SegLossConfig, SegmentationLoss
 
 # modules imported (if importable) before the scan, so that install() may run before OR after the reference is imported
 _PRELOAD = ("ultralytics.nn.tasks", "mga_yolo.external.ultralytics.ultralytics.nn.tasks",
-            "mga_yolo.nn.modules.masked_cbam", "mga_yolo.nn.modules.masked_eca", "mga_yolo.nn.losses.segmentation")
+            "mga_yolo.nn.modules.masked_cbam", "mga_yolo.nn.modules.masked_eca", "mga_yolo.nn.modules.segmentation",
+            "mga_yolo.nn.losses.segmentation", "mga_yolo.model.model")
 _PREFIXES = ("ultralytics", "mga_yolo")
 _TASKS_SUFFIX = "ultralytics.nn.tasks"
 # name -> replacement.  parse_model treats MaskCBAM and MaskECA through the same branch (U/nn/tasks.py:1733)
-_CLASSES: Dict[str, type] = {"MaskCBAM": MaskCBAM, "MaskECA": MaskECA,
+_CLASSES: Dict[str, type] = {"MaskCBAM": MaskCBAM, "MaskECA": MaskECA, "MGAMaskHead": MGAMaskHead,
                              "SegmentationLoss": SegmentationLoss, "SegLossConfig": SegLossConfig}
 
 
@@ -61,7 +62,7 @@ def install(strict: bool = False) -> List[str]:
                 hit = True
                 continue
             # a class of that name (the reference's own), or the `= None` left by tasks.py's guarded import (U/nn/tasks.py:72-90)
-            if (isinstance(cur, type) and cur.__name__ == cls_name) or (is_tasks and cur is None and cls_name in ("MaskCBAM", "MaskECA")):
+            if (isinstance(cur, type) and cur.__name__ == cls_name) or (is_tasks and cur is None and cls_name in ("MaskCBAM", "MaskECA", "MGAMaskHead")):
                 _UNDO.append((name, cls_name, cur))
                 setattr(mod, cls_name, cls)
                 hit = True

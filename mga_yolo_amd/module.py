@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .functional import BlockConfig, EcaConfig, mask_cbam, mask_eca, prob_mask_gate
+from .functional import BlockConfig, EcaConfig, mask_cbam, mask_eca, mask_head, prob_mask_gate
 
 _GATER_MODES = ("deterministic", "gumbel", "hard_st", "bernoulli_detach")
 
@@ -267,3 +267,87 @@ def _eca_host_forward(x, mask, w, beta, cfg: EcaConfig) -> torch.Tensor:
         v = masked * valid + gap * (1.0 - valid)
     gate = torch.sigmoid(F.conv1d(v.unsqueeze(1).to(w.dtype), w, padding=cfg.k // 2).squeeze(1)).view(B, Cc, 1, 1)
     return x * (1.0 + F.softplus(beta).to(gate.dtype) * (gate - 0.5)).to(x.dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# MGAMaskHead: mirror of mga_yolo/nn/modules/segmentation.py:34-127
+# ---------------------------------------------------------------------------------------------------------
+class _HeadCfg:
+    """Attribute bag with the reference dataclass's field names (segmentation.py:35-53)."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, norm, act, dropout):
+        self.in_channels, self.hidden_channels, self.out_channels = in_channels, hidden_channels, out_channels
+        self.norm, self.act, self.dropout = norm, act, dropout
+
+
+class ChannelLastLayerNorm(nn.Module):
+    """LayerNorm over the channel axis of an NCHW tensor (segmentation.py:114-126); only built for norm="ln"."""
+
+    def __init__(self, num_channels: int, eps: float = 1e-6) -> None:
+        super().__init__()
+        self.ln = nn.LayerNorm(num_channels, eps=eps)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.ln(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+
+
+class MGAMaskHead(nn.Module):
+    """Coarse mask head of one pyramid level: Conv1x1(in -> hidden, no bias) -> BatchNorm2d -> SiLU -> Conv3x3(hidden -> 1) + bias,
+    producing the LOGITS MaskCBAM takes as its mask and the segmentation loss is computed on.  Drop-in for the reference class:
+    same constructor, same state_dict (``proj.0.weight``, ``proj.1.{weight,bias,running_mean,running_var,num_batches_tracked}``,
+    ``head.{weight,bias}``), same initialisation order (kaiming_normal fan_out for the convs, BatchNorm ones / zeros), ``cfg`` and
+    ``extra_repr``.  The containers hold the parameters; for device tensors in the configuration every reference YAML uses
+    (norm="bn", act=SiLU, dropout=0, out_channels=1) the math runs in the HIP kernels (the 1x1 conv and its backward products on the
+    matrix cores), BatchNorm's running statistics updated in place as torch does.  Host tensors and other constructor variants run
+    the containers' own torch ops."""
+
+    def __init__(self, in_channels: int, hidden_channels: int, out_channels: int = 1, norm: Optional[str] = "bn",
+                 act: type = nn.SiLU, dropout: float = 0.0) -> None:
+        super().__init__()
+        self.cfg = _HeadCfg(in_channels, hidden_channels, out_channels, norm, act, dropout)
+        layers = [nn.Conv2d(in_channels, hidden_channels, kernel_size=1, bias=False)]
+        if norm == "bn":
+            layers.append(nn.BatchNorm2d(hidden_channels))
+        elif norm == "ln":
+            layers.append(ChannelLastLayerNorm(hidden_channels))
+        if act is not None:
+            layers.append(act())
+        if dropout and dropout > 0:
+            layers.append(nn.Dropout2d(p=dropout))
+        self.proj = nn.Sequential(*layers)
+        self.head = nn.Conv2d(hidden_channels, out_channels, kernel_size=3, padding=1, bias=True)
+        self._initialize()
+
+    def _initialize(self) -> None:                              # segmentation.py:96-104 (same module traversal order)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, (nn.BatchNorm2d, nn.LayerNorm)):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def hip_path(self) -> bool:
+        """True when the configuration is the one the HIP kernels implement."""
+        c = self.cfg
+        if not (c.norm == "bn" and c.act is nn.SiLU and not (c.dropout and c.dropout > 0) and c.out_channels == 1):
+            return False
+        bn = self.proj._modules["1"]
+        return bool(bn.affine and bn.track_running_stats and bn.momentum is not None and bn.running_mean is not None)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:         # (B, C_in, H, W) -> (B, C_out, H, W) logits
+        if x.is_cuda and self.hip_path():
+            conv, bn = self.proj._modules["0"], self.proj._modules["1"]
+            return mask_head(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                             self.head.weight, self.head.bias, eps=bn.eps, momentum=bn.momentum, training=self.training)
+        if x.is_cuda and not self.__dict__.get("_warned_variant"):
+            import warnings
+            warnings.warn("MGAMaskHead: constructor variant outside the HIP path (norm / act / dropout / out_channels); running torch ops")
+            self.__dict__["_warned_variant"] = True
+        return self.head(self.proj(x))
+
+    def extra_repr(self) -> str:
+        c = self.cfg
+        return (f"in={c.in_channels}, hidden={c.hidden_channels}, out={c.out_channels}, norm={c.norm}, "
+                f"act={c.act.__name__ if c.act else None}, dropout={c.dropout}")

@@ -52,3 +52,170 @@ def test_oracle_matches_the_reference_golden(name):
     y2, gx2 = HO.reference_form_step(d["x"], p, d["g"], training=m["training"])
     _close(y2, d["out"]["logits"], 1e-6, "eager-op form logits")
     _close(gx2, d["out"]["gx"], 1e-6, "eager-op form gx")
+
+
+def _module_from_golden(d, device="cpu"):
+    from mga_yolo_amd import MGAMaskHead
+    hid, C = d["params"]["proj.0.weight"].shape[:2]
+    m = MGAMaskHead(C, hid)
+    m.load_state_dict(d["params"], strict=True)                  # a reference state_dict loads as is
+    bn = m.proj[1]
+    bn.eps, bn.momentum = d["meta"]["eps"], d["meta"]["momentum"]
+    m.train(d["meta"]["training"])
+    return m.to(device)
+
+
+def _check_module(d, m, dev, tol):
+    x = d["x"].to(dev).requires_grad_(True)
+    y = m(x)
+    y.backward(d["g"].to(dev))
+    o = d["out"]
+    _close(y.detach().cpu(), o["logits"], tol, "logits")
+    _close(x.grad.cpu(), o["gx"], tol, "gx")
+    p = dict(m.named_parameters())
+    for k, name in (("gw1", "proj.0.weight"), ("ggamma", "proj.1.weight"), ("gbeta", "proj.1.bias"), ("gwh", "head.weight"), ("gbh", "head.bias")):
+        _close(p[name].grad.cpu(), o[k], tol, k)
+    sd = m.state_dict()
+    _close(sd["proj.1.running_mean"].cpu(), o["running_mean"], tol, "running_mean")
+    _close(sd["proj.1.running_var"].cpu(), o["running_var"], tol, "running_var")
+    assert int(sd["proj.1.num_batches_tracked"]) == int(o["num_batches_tracked"])
+
+
+@pytest.mark.parametrize("name", head_golden_names())
+def test_module_host_path_matches_the_reference_golden(name):
+    d = load_head_golden(name)
+    _check_module(d, _module_from_golden(d), "cpu", 2e-5)
+
+
+def test_module_mirror_contract():
+    """Same constructor / state_dict / initialisation order as the reference class (segmentation.py:56-104): the same seed gives the
+    same initial values (recorded in the p3_like golden, which was built at seed 0 without perturbation)."""
+    from mga_yolo_amd import MGAMaskHead
+    d = load_head_golden("p3_like")
+    torch.manual_seed(0)
+    m = MGAMaskHead(64, 16)
+    sd = m.state_dict()
+    assert list(sd) == list(d["params"])
+    for k, v in d["params"].items():
+        assert torch.equal(sd[k], v), k
+    assert m.cfg.in_channels == 64 and m.cfg.hidden_channels == 16 and m.cfg.out_channels == 1 and m.cfg.norm == "bn"
+    assert "in=64, hidden=16, out=1, norm=bn, act=SiLU, dropout=0.0" in repr(m)
+    assert m.hip_path()
+    import copy, pickle
+    assert torch.equal(copy.deepcopy(m).head.weight, m.head.weight) and pickle.loads(pickle.dumps(m)).cfg.hidden_channels == 16
+    # constructor variants keep the reference's structure (served by torch ops)
+    v = MGAMaskHead(32, 8, out_channels=2, norm="ln", act=torch.nn.ReLU, dropout=0.1)
+    assert not v.hip_path() and list(v.state_dict()) == ["proj.0.weight", "proj.1.ln.weight", "proj.1.ln.bias", "head.weight", "head.bias"]
+    assert v(torch.randn(1, 32, 5, 5)).shape == (1, 2, 5, 5)
+    assert MGAMaskHead(8, 8, norm=None, act=None)(torch.randn(1, 8, 3, 3)).shape == (1, 1, 3, 3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", head_golden_names())
+def test_device_path_matches_the_reference_golden(built_lib, name):
+    """HIP path (C ABI mgahead_forward / mgahead_backward through the module) vs what the reference's own MGAMaskHead produced:
+    logits, every gradient, BatchNorm running statistics and num_batches_tracked."""
+    d = load_head_golden(name)
+    m = _module_from_golden(d, "cuda")
+    assert m.hip_path()
+    _check_module(d, m, "cuda", TOL)
+    assert "libmgacbam.so" in open("/proc/self/maps").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cfg2_p3", "cfg2_p4", "cfg2_p5", "cfg3_p3", "cfg3_p4", "cfg3_p5"])
+def test_device_full_size_checksums_vs_reference(built_lib, name):
+    from mga_yolo_amd import MGAMaskHead
+    ref = json.load(open(os.path.join(GOLDEN, "head_checksums.json")))["big"][name]
+    B, C, hid, H, W = ref["shape"]
+    torch.manual_seed(0)
+    m = MGAMaskHead(C, hid)
+    m.proj[1].eps, m.proj[1].momentum = ref["eps"], ref["momentum"]
+    m.cuda().train()
+    g = torch.Generator().manual_seed(1234)                        # the recipe of oracle/gen_golden_head.py:data()
+    x = torch.randn(B, C, H, W, generator=g)
+    gl = torch.randn(B, 1, H, W, generator=g)
+    xd = x.cuda().requires_grad_(True)
+    y = m(xd)
+    y.backward(gl.cuda())
+    p = dict(m.named_parameters())
+    got = dict(logits=y.detach(), gx=xd.grad, gw1=p["proj.0.weight"].grad, ggamma=p["proj.1.weight"].grad, gbeta=p["proj.1.bias"].grad,
+               gwh=p["head.weight"].grad, gbh=p["head.bias"].grad, running_mean=m.proj[1].running_mean, running_var=m.proj[1].running_var)
+    report = []
+    for k, v in got.items():
+        c = checksum(v.float())
+        scale = ref[k]["abs"] + 1e-12
+        for f in ("sum", "wsum", "abs"):
+            if not abs(c[f] - ref[k][f]) <= TOL * scale:
+                report.append(f"{k}.{f}: got {c[f]:.6f} want {ref[k][f]:.6f}")
+    assert not report, f"{name}: " + "; ".join(report)
+    # run-to-run reproducibility (fixed-order sums, no float atomics)
+    m.zero_grad(); xd.grad = None
+    y2 = m(xd); y2.backward(gl.cuda())
+    assert torch.equal(y2, y) and torch.equal(xd.grad, got["gx"]) and torch.equal(p["proj.0.weight"].grad, got["gw1"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+def test_device_half_precision_io(built_lib, dtype, tol):
+    """fp16 / bf16 features and logits with fp32 accumulation and fp32 parameters, against the fp32 oracle on the rounded inputs."""
+    from mga_yolo_amd import MGAMaskHead
+    torch.manual_seed(3)
+    m = MGAMaskHead(128, 32).cuda().train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 128, 20, 20, generator=g).to(dtype)
+    gl = torch.randn(4, 1, 20, 20, generator=g).to(dtype)
+    p = HO.HeadParams.from_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    lo, c = HO.forward(x.float(), p, True)
+    go = HO.backward(gl.float(), x.float(), p, c, True)
+    xd = x.cuda().requires_grad_(True)
+    y = m(xd)
+    assert y.dtype == dtype
+    y.backward(gl.cuda())
+    assert xd.grad.dtype == dtype
+    assert rel_err(y.float(), lo) < tol and rel_err(xd.grad.float(), go["gx"]) < tol
+    assert rel_err(m.proj[0].weight.grad.reshape(32, 128), go["gw1"]) < tol and rel_err(m.head.weight.grad, go["gwh"]) < tol
+
+
+@pytest.mark.gpu
+def test_device_pyramid_call_and_layer_loop_hand_off(built_lib):
+    """The three heads in ONE library call each way == three module calls; and the layer-loop hand-off of the reference
+    (mga_yolo/model/model.py:57-74): head -> [feat, mask] -> MaskCBAM, one backward through both, against the oracles."""
+    from mga_yolo_amd import MGAMaskHead, MaskCBAM, mask_head_pyramid
+    from oracle import maskcbam_oracle as CO
+    shapes = [(4, 64, 16, 16, 16), (4, 128, 8, 8, 32), (4, 256, 4, 4, 64)]
+    mods, xs = [], []
+    for i, (B, C, H, W, hid) in enumerate(shapes):
+        torch.manual_seed(i)
+        mods.append(MGAMaskHead(C, hid).cuda().train())
+        xs.append(torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(40 + i)).cuda())
+    single = [m(x) for m, x in zip(mods, xs)]
+    for m in mods:                                                # the second call must start from the same running statistics
+        m.proj[1].reset_running_stats()
+    lv = []
+    for m, x in zip(mods, xs):
+        bn = m.proj[1]
+        lv.append((x, m.proj[0].weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, m.head.weight,
+                   m.head.bias, bn.eps, bn.momentum, True))
+    for a, b in zip(mask_head_pyramid(lv), single):
+        assert torch.equal(a, b)
+    # hand-off: logits -> MaskCBAM mask input; gradient flows back through the block into the head
+    B, C, H, W, hid = shapes[0]
+    torch.manual_seed(0)
+    head, blk = MGAMaskHead(C, hid).cuda().train(), MaskCBAM(C).cuda()
+    x = xs[0].clone().requires_grad_(True)
+    gy = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(9)).cuda()
+    y = blk([x, head(x)])
+    y.backward(gy)
+    hp = HO.HeadParams.from_state_dict({k: v.detach().cpu() for k, v in head.state_dict().items()})
+    hp.running_mean.zero_(); hp.running_var.fill_(1.0)           # (the state_dict was read after the forward updated them)
+    xc = x.detach().cpu()
+    logits, hc = HO.forward(xc, hp, True)
+    cp = CO.Params.from_state_dict({k: v.detach().cpu() for k, v in blk.state_dict().items()})
+    y_o, cc = CO.forward(xc, logits, cp)
+    g_o = CO.backward(gy.cpu(), xc, logits, cp, CO.Config(), cc)
+    gh = HO.backward(g_o["gmask"], xc, hp, hc, True)
+    assert rel_err(y, y_o) < TOL
+    assert rel_err(x.grad, g_o["gx"] + gh["gx"]) < TOL             # the feature feeds both the block and its mask head
+    assert rel_err(head.proj[0].weight.grad.reshape(hid, C), gh["gw1"]) < TOL and rel_err(head.head.weight.grad, gh["gwh"]) < TOL

@@ -37,11 +37,16 @@ def nograd():
         fwd()
 
 
+leaves = xs + ms + [p for m in mods for p in m.parameters()]
+
+
 def step():
+    for t in leaves:          # zero_grad(set_to_none=True): without it autograd ADDS into last step's gradients (24 extra kernels)
+        t.grad = None
     torch.autograd.backward(fwd(), gys)
 
 
-for name, fn in (("forward, no_grad", nograd), ("forward, grad mode", fwd), ("forward + backward", step)):
+for name, fn in (("forward + backward", step), ("forward, no_grad", nograd), ("forward, grad mode", fwd), ("forward + backward", step)):
     h, t = timeit(fn)
     print(f"{name:22s} host enqueue {h:7.1f} us   wall {t:7.1f} us")
 pr = cProfile.Profile(); pr.enable()

@@ -16,7 +16,12 @@ for C, H, W in LV:
     gys.append(torch.randn(B, C, H, W, device="cuda"))
 
 
+leaves = xs + ms + [p for m in mods for p in m.parameters()]
+
+
 def step():
+    for t in leaves:          # zero_grad(set_to_none=True): without it autograd ADDS into last step's gradients (24 extra kernels)
+        t.grad = None
     ys = [m([x, k]) for m, x, k in zip(mods, xs, ms)]
     torch.autograd.backward(ys, gys)
 

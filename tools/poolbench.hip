@@ -8,22 +8,24 @@
 
 template <int CPT, int LEVEL>   // LEVEL 0: x only; 1: + mask load; 2: + sigmoid & sxs; 3: + argmax; 4: + block reduction epilogue
 __global__ __launch_bounds__(256) void k(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ out,
-                                         int B, int C, int HW, int TX) {
+                                         int B, int C, int HW, int TX, int S = 1) {
   __shared__ float red[64];
   const int tid = threadIdx.x;
   const int lt = 31 - __clz(TX);
   const int tx = tid & (TX - 1), ty = tid >> lt, TY = 256 >> lt;
   const int CPB = TY * CPT, ncg = C / CPB;
-  const int b = blockIdx.x / ncg, cg = blockIdx.x % ncg;
+  const int part = blockIdx.x % S, bq = blockIdx.x / S;       // S-way split of the H*W sweep over workgroups (partials combined later)
+  const int b = bq / ncg, cg = bq % ncg;
   const int c0 = cg * CPB + ty * CPT;
-  const int nv = HW / 4;
+  const int nvt = HW / 4, nvp = (nvt + S - 1) / S;
+  const int v0 = part * nvp, nv = min(nvt, v0 + nvp);
   const float4* xr[CPT];
   for (int j = 0; j < CPT; ++j) xr[j] = reinterpret_cast<const float4*>(x + ((size_t)b * C + c0 + j) * HW);
   const float4* mb = reinterpret_cast<const float4*>(mask + (size_t)b * HW);
   float sx[CPT], sxs[CPT], vmax[CPT]; int imax[CPT];
   for (int j = 0; j < CPT; ++j) { sx[j] = 0; sxs[j] = 0; vmax[j] = -FLT_MAX; imax[j] = 0; }
   float ssum = 0;
-  for (int i = tx; i < nv; i += TX) {
+  for (int i = v0 + tx; i < nv; i += TX) {
     float s[4] = {1, 1, 1, 1}; bool sel[4] = {true, true, true, true};
     if (LEVEL >= 1) {
       float4 m = mb[i]; float mm[4] = {m.x, m.y, m.z, m.w};
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ x, const floa
       __syncthreads();
       if (tx == 0) for (int j = 0; j < CPT; ++j) for (int w = 1; w < TX / 64; ++w) { sx[j] += red[((tid >> 6) + w) * CPT + j]; sxs[j] += red[32 + ((tid >> 6) + w) * CPT + j]; }
     }
-    if (tx == 0) for (int j = 0; j < CPT; ++j) { out[((size_t)b * C + c0 + j) * 4] = sx[j] + ssum; out[((size_t)b * C + c0 + j) * 4 + 1] = sxs[j]; out[((size_t)b * C + c0 + j) * 4 + 2] = vmax[j]; out[((size_t)b * C + c0 + j) * 4 + 3] = (float)imax[j]; }
+    if (tx == 0) for (int j = 0; j < CPT; ++j) { out[(((size_t)b * C + c0 + j) * S + part) * 4] = sx[j] + ssum; out[(((size_t)b * C + c0 + j) * S + part) * 4 + 1] = sxs[j]; out[(((size_t)b * C + c0 + j) * S + part) * 4 + 2] = vmax[j]; out[(((size_t)b * C + c0 + j) * S + part) * 4 + 3] = (float)imax[j]; }
   } else {
     float t = ssum;
     for (int j = 0; j < CPT; ++j) t += sx[j] + sxs[j] + vmax[j] + imax[j];
@@ -73,7 +75,7 @@ int main(int argc, char** argv) {
   printf("B=%d C=%d HW=%d (%.1f MB)\n", B, C, HW, B * (double)C * HW * 4 / 1e6);
   const size_t n = (size_t)B * C * HW;
   float *x, *m, *o;
-  CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&m, (size_t)B * HW * 4)); CK(hipMalloc(&o, (size_t)B * C * 16));
+  CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&m, (size_t)B * HW * 4)); CK(hipMalloc(&o, (size_t)B * C * 16 * 8));
   CK(hipMemset(x, 0, n * 4)); CK(hipMemset(m, 0, (size_t)B * HW * 4));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto run = [&](const char* name, auto launch) {
@@ -89,5 +91,8 @@ int main(int argc, char** argv) {
   RUN(1, 0, 256); RUN(1, 4, 256); RUN(4, 0, 256); RUN(4, 1, 256); RUN(4, 2, 256); RUN(4, 3, 256); RUN(4, 4, 256);
   RUN(2, 0, 64); RUN(2, 4, 64); RUN(1, 0, 64); RUN(1, 4, 64); RUN(4, 4, 64);
   RUN(2, 0, 128); RUN(2, 4, 128);
+#define RUNS(CPT, LEVEL, TX, S) run("cpt" #CPT " level" #LEVEL " tx" #TX " split" #S, [&] { hipLaunchKernelGGL((k<CPT, LEVEL>), dim3(S * B * C / ((256 / TX) * CPT)), dim3(256), 0, 0, x, m, o, B, C, HW, TX, S); })
+  RUNS(2, 0, 256, 2); RUNS(2, 4, 256, 2); RUNS(2, 0, 256, 4); RUNS(2, 4, 256, 4); RUNS(2, 4, 256, 8); RUNS(1, 4, 256, 2); RUNS(1, 4, 256, 4); RUNS(4, 4, 256, 4); RUNS(4, 4, 256, 8);
+  RUNS(2, 4, 64, 2); RUNS(2, 4, 64, 4); RUNS(2, 4, 128, 4);
   return 0;
 }
