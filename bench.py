@@ -192,6 +192,45 @@ def eager_module_step(workload, device, dtype_name, steps=60, warmup=10):
     return (time.perf_counter() - t0) * 1e3 / steps
 
 
+def slice_step(workload, device, steps=100, warmup=10):
+    """SURVEY 8d images/s definition (2), in scope: the LAYER-LOOP SLICE of the training step (mga_yolo_amd/slice.py) -- three mask heads,
+    three MaskCBAM blocks, the multi-scale segmentation loss, the Kendall combine and the backward of all of it, replayed from one
+    hipGraph.  Backbone / neck / Detect / detection loss are out of scope: they enter as given tensors (dL/d refined, det_loss)."""
+    import torch
+    from mga_yolo_amd import MGAMaskHead, MaskCBAM
+    from mga_yolo_amd.slice import SlicePlan
+    desc, batch, lv = WORKLOADS[workload]
+    shapes, hidden, cps, cfgs, hss = [], [], [], [], []
+    for (C, H, W) in lv:
+        torch.manual_seed(0)
+        m = MaskCBAM(C)
+        hid = max(8, ((C // 4) + 7) // 8 * 8)                    # yolov8_cbam.yaml: MGAMaskHead [C*4, C] width-scaled -> hidden = C / 4
+        h = MGAMaskHead(C, hid)
+        shapes.append((batch, C, H, W)); hidden.append(hid); cps.append(m.block_params()); cfgs.append(m.block_config()); hss.append(h.state_dict())
+    plan = SlicePlan(shapes, hidden, cps, cfgs, hss, device=device)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for l, (B, C, H, W) in enumerate(shapes):
+        plan.x[l].copy_(torch.nn.functional.silu(torch.randn(B, C, H, W, generator=g)))
+        plan.gy[l].copy_(torch.randn(B, C, H, W, generator=g))
+        plan.targets[l].copy_((torch.rand(B, 1, H, W, generator=g) > 0.9).float())
+    plan.det_loss.copy_(torch.tensor([1.0, 0.5, 1.5]))
+    graph = plan.capture(plan.step)
+    for _ in range(warmup):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    plan.check_handoff()
+    E = sum(B * C * H * W for B, C, H, W in shapes) * 4
+    # algorithmic bytes of the slice: MaskCBAM 8 E; head forward reads x (1 E) + writes / reads z (2 * E/4); head backward reads x (1 E),
+    # accumulates gx (read + write 2 E), g_a / z traffic 4 * E/4
+    return dict(ms_per_step=round(ms, 4), images_per_s=round(batch / (ms * 1e-3), 1), hidden=hidden, launches=plan.launches(),
+                note="mask heads + MaskCBAM + seg loss + Kendall, fwd + bwd, one hipGraph; dL/d(refined) and det_loss are given")
+
+
 def host_cpu_info():
     model = "unknown"
     try:
@@ -405,6 +444,9 @@ def main():
         eager_ms = round(eager_module_step(args.workload, device, args.dtype), 4)
         from mga_yolo_amd import handoff_report
         handoff_report()
+    slice_res = None
+    if rank == 0 and world == 1 and not args.no_eager and args.dtype == "f32":
+        slice_res = slice_step(args.workload, device)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, args.cpu_seconds)
@@ -419,7 +461,7 @@ def main():
                                 grad_exchange=None if world == 1 else f"{'RCCL' if args.backend == 'nccl' else args.backend} all-reduce of one {plan.grad_bucket.numel() * 4} B bucket per step, overlapped with the next step's parameter-free k_pool",
                                 handoff_kernels=bool(plan.fuse_forward)),
                     roofline=roofline, step_roofline=step_roof, kernels=kernels, cpu_baseline=cpu,
-                    eager_module_ms_per_step=eager_ms,
+                    eager_module_ms_per_step=eager_ms, layer_loop_slice=slice_res,
                     eager_module_note="the unchanged reference layer loop's path: three MaskCBAM modules through autograd, one library call per level each way, launches issued from Python (no PyramidPlan / hipGraph)",
                     lib=_lib.load().mgacbam_build_info().decode())
         print(json.dumps(line))

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MGACBAM_ABI_VERSION 10
+#define MGACBAM_ABI_VERSION 12
 #define MGACBAM_MAX_LEVELS 8          /* P3/P4/P5 need 3 */
 
 enum { MGACBAM_F32 = 0, MGACBAM_F16 = 1, MGACBAM_BF16 = 2 };
@@ -308,6 +308,8 @@ typedef struct mgahead_fwd_level {
 typedef struct mgahead_bwd_level {
   const void* x;               /* as in forward                                                */
   const void* g_logits;        /* (B,1,H,W) dL/dlogits of `dtype`                              */
+  const float* g_logits2;      /* optional second addend of dL/dlogits, fp32 (B,1,H,W), or NULL: the logits feed the segmentation loss AND
+                                  MaskCBAM (model.py:57-64, 196-202); passing MaskCBAM's dL/dmask here saves the add launch */
   const void* ctx;             /* written by the matching forward                              */
   void* scratch;               /* mgahead_bwd_scratch_bytes(), contents undefined              */
   void* gx;                    /* (B,C,H,W) dL/dx of `dtype`                                   */
@@ -319,7 +321,11 @@ typedef struct mgahead_bwd_level {
   mgahead_params_t p;          /* training as in the forward; running statistics are not touched */
   int32_t B, C, H, W;
   int32_t dtype;
+  int32_t flags;               /* MGAHEAD_BWD_ACCUM_GX: gx already holds the gradient of the feature's OTHER consumer (in the layer loop the
+                                  feature feeds both its mask head and its MaskCBAM, model.py:57-64) and this call ADDS to it in the GEMM
+                                  epilogue -- the feature-sized add autograd would do as a pass of its own disappears            */
 } mgahead_bwd_level_t;
+enum { MGAHEAD_BWD_ACCUM_GX = 1 };
 
 size_t mgahead_ctx_bytes(int B, int C, int H, int W, int hidden);
 size_t mgahead_bwd_scratch_bytes(int B, int C, int H, int W, int hidden);

@@ -8,7 +8,7 @@ import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGACBAM_LIB") or os.path.join(_PKG, "libmgacbam.so")   # MGACBAM_LIB: A/B builds in tuning sweeps
-ABI_VERSION = 10
+ABI_VERSION = 12
 MAX_LEVELS = 8
 F32, F16, BF16 = 0, 1, 2
 # stage bit masks (include/mgacbam.h)
@@ -96,9 +96,13 @@ class HeadFwdLevel(C.Structure):                 # mgahead_fwd_level_t
 
 
 class HeadBwdLevel(C.Structure):                 # mgahead_bwd_level_t
-    _fields_ = [("x", C.c_void_p), ("g_logits", C.c_void_p), ("ctx", C.c_void_p), ("scratch", C.c_void_p), ("gx", C.c_void_p),
+    _fields_ = [("x", C.c_void_p), ("g_logits", C.c_void_p), ("g_logits2", C.c_void_p), ("ctx", C.c_void_p), ("scratch", C.c_void_p), ("gx", C.c_void_p),
                 ("gw1", C.c_void_p), ("gbn_weight", C.c_void_p), ("gbn_bias", C.c_void_p), ("gwh", C.c_void_p), ("gbh", C.c_void_p),
-                ("p", HeadParams), ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dtype", C.c_int32)]
+                ("p", HeadParams), ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dtype", C.c_int32),
+                ("flags", C.c_int32)]
+
+
+HEAD_BWD_ACCUM_GX = 1
 
 
 class PmgCfg(C.Structure):                       # mgapmg_cfg_t

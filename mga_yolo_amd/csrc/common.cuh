@@ -99,19 +99,65 @@ __device__ __forceinline__ bool isclosef_(float a, float b) { return fabsf(a - b
 // wave (groups are TX-aligned so xor offsets < TX never leave the group) and, when a row spans
 // several waves (TX = 128, 256), a second step through LDS.
 // ---------------------------------------------------------------------------------------------
+// Sums inside aligned groups of `width` lanes (power of two, 1..64); every lane of the group gets the group's sum.
+// DPP forms, not __shfl_xor: a shuffle compiles to ds_bpermute_b32, i.e. one trip through the LDS crossbar per step and value -- in the
+// kernels that reduce per channel (k_bwd_reduce1: 2 sums x log2(TX) steps per channel and wave; the mask head's backward: 12 sums per
+// channel) that traffic, shared by every wave of the CU, costs more than the arithmetic.  quad_perm / row_mirror / row_bcast run in the
+// VALU.  After the two quad steps every quad holds its sum in all four lanes, so mirroring within 8 and within 16 lanes pairs each
+// half with the other one (same effect as xor 4 / xor 8); across the four rows of 16: row_bcast15 / row_bcast31 (gfx9 DPP) leave
+// S0+S1 in lane 31 and the wave's total in lane 63, which v_readlane hands to every lane.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_add(float v) {
+  // lanes whose row is masked out (or whose source is invalid) receive `old` = 0
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_group_sum(float v, int width) {
-  for (int o = (width < kWave ? width : kWave) >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+  if (width >= 2) v = dpp_add<0xB1>(v);                         // quad_perm [1,0,3,2]
+  if (width >= 4) v = dpp_add<0x4E>(v);                         // quad_perm [2,3,0,1]
+  if (width >= 8) v = dpp_add<0x141>(v);                        // row_half_mirror
+  if (width >= 16) v = dpp_add<0x140>(v);                       // row_mirror: every lane of a row of 16 holds the row's sum
+  if (width >= 32) {
+    v = dpp_add<0x142, 0xA>(v);                                 // row_bcast15 into rows 1 and 3: lanes 16..31 = S0+S1, 48..63 = S2+S3
+    if (width >= 64) {
+      v = dpp_add<0x143, 0xC>(v);                               // row_bcast31 into rows 2 and 3: lane 63 = S0+S1+S2+S3
+      v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    } else {
+      const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+      const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+      v = (threadIdx.x & 32) ? hi : lo;
+    }
+  }
   return v;
 }
 // (value, index) arg-max with first-index tie break: larger value wins, equal values -> smaller index
 __device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int oi) {
   if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
+// the same DPP steps for (value, index) pairs; lanes a step does not reach combine with themselves (old = own value: a no-op)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ void dpp_argmax(float& v, int& i) {
+  const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+  const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xF, false);
+  argmax_combine(v, i, ov, oi);
+}
 __device__ __forceinline__ void wave_group_argmax(float& v, int& i, int width) {
-  for (int o = (width < kWave ? width : kWave) >> 1; o > 0; o >>= 1) {
-    float ov = __shfl_xor(v, o, kWave);
-    int oi = __shfl_xor(i, o, kWave);
-    argmax_combine(v, i, ov, oi);
+  if (width >= 2) dpp_argmax<0xB1>(v, i);
+  if (width >= 4) dpp_argmax<0x4E>(v, i);
+  if (width >= 8) dpp_argmax<0x141>(v, i);
+  if (width >= 16) dpp_argmax<0x140>(v, i);
+  if (width >= 32) {
+    dpp_argmax<0x142, 0xA>(v, i);
+    if (width >= 64) {
+      dpp_argmax<0x143, 0xC>(v, i);
+      v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+      i = __builtin_amdgcn_readlane(i, 63);
+    } else {
+      const float vlo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+      const float vhi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+      const int ilo = __builtin_amdgcn_readlane(i, 31), ihi = __builtin_amdgcn_readlane(i, 63);
+      const bool up = (threadIdx.x & 32) != 0;
+      v = up ? vhi : vlo; i = up ? ihi : ilo;
+    }
   }
 }
 

@@ -41,28 +41,33 @@ struct HeadPtrs {
   const float* wh;     // (1, hid, 3, 3)  head.weight
   const float* bh;     // (1)             head.bias
 };
-// ctx (saved for backward): z (B,hid,HW) fp32 | mean[hidp] | rstd[hidp] | part (nwg, 2, hidp)
-struct HeadCtx { float* z; float* mean; float* rstd; float* part; };
-// scratch (backward transients): g_a (B,hid,HW) | part1 (nwg1, hidp, 12) | kst (5, hidp) | gwpart (ncb*kHeadGwWG, hidp, kHeadCB)
+// ctx (saved for backward): z (B,hid,HW) fp32 | mean[hidp] | rstd[hidp] | par [hidp][16] | part (nwg, 2, hidp)
+//   par[j] = {scale = gamma*rstd, shift = beta - mean*scale, mean, rstd, W_h[j][0..8]}: written by k_head_stats, read with SCALAR loads
+//   (uniform address -> s_load / SGPR operands) by k_head_out and k_head_bwd_act instead of LDS broadcasts
+struct HeadCtx { float* z; float* mean; float* rstd; float* par; float* part; };
+constexpr int kHeadPar = 16;
+// scratch (backward transients): g_a (B,hid,HW) | part1 (nwg1, hidp, 12) | kst (5, hidp) | gwpart (ncb*nshare, hidp, kHeadCB)
 struct HeadScratch { float* ga; float* part1; float* kst; float* gwpart; };
 
 struct HeadArgs {
   const void* x; void* logits;                 // forward
   const void* gl; void* gx;                    // backward: dL/dlogits (B,1,H,W) T, dL/dx (B,C,H,W) T
+  const float* gl2;                            // optional second addend of dL/dlogits (fp32), or null
   float* gw1; float* ggamma; float* gbeta; float* gwh; float* gbh;
   HeadPtrs p; HeadCtx c; HeadScratch s; HeadGeo g;
   int tile_px, tiles_per_sample, nwg;          // 1-D pixel tiling of k_head_gemm<FWD> (nwg = rows of the partial sums)
   int gx_tile_px, gx_tiles_per_sample;         // ... of k_head_gemm<GX>
-  int t2x, t2y, nwg1;                          // 2-D tiling of the conv kernels (k_head_out, k_head_bwd_act): tiles per row / column / level
-  int ncb;                                     // channel blocks of k_head_bwd_gw
+  int fw_kw, gx_kw;                            // waves of a workgroup that split the K steps (1, 2, 4)
+  int nwg_out, out_hl_max;                     // k_head_out: workgroups (runs of kHeadOutPx pixels), LDS floats per staged channel (launch maximum)
+  int nwg1, act_ppt, act_hl_max;               // k_head_bwd_act: pixel runs of the level, pixels per thread, LDS floats of the launch's longest run
+  int ncb, nshare;                             // k_head_bwd_gw: channel blocks, pixel shares per block (= partial sets of dW1)
+  int accum_gx;                                // MGAHEAD_BWD_ACCUM_GX: gx += W1^T g_z
 };
 
 constexpr int kHeadMTW = 4;      // 16-output tiles a wave accumulates at once (x VEC sub-tiles x 4 registers)
-constexpr int kHeadLdsA = 8192;  // floats of LDS for the staged A operand (32 KB)
-constexpr int kHeadT2 = 16;      // k_head_out / k_head_bwd_act: 16 x 16 pixel tiles
-constexpr int kHeadJC = 16;      // ... hidden channels per LDS pass
+constexpr int kHeadLdsA = 4096;  // floats of LDS for the staged A operand (16 KB: one launch covers all levels, so the largest level's block sets every level's occupancy)
+constexpr int kHeadJC = 4;       // k_head_bwd_act: hidden channels per workgroup (= one batch of z loads: every workgroup is one memory round trip deep)
 constexpr int kHeadCB = 64;      // k_head_bwd_gw: channels of x per workgroup (4 N tiles)
-constexpr int kHeadGwWG = 96;    // k_head_bwd_gw: workgroups per (level, channel block) = partial sets of dW1
 constexpr int kHeadNStat = 12;   // per-channel partial sums of k_head_bwd_act: g_a, g_a*zhat, 9 taps of dW_h, db_h
 __device__ __forceinline__ float siluf(float a) { return a / (1.f + expf(-a)); }
 
@@ -85,8 +90,11 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
   const int MT = ((GX ? g.cp : g.hidp)) >> 4;
   const int MW = min(4, (MT + kHeadMTW - 1) / kHeadMTW);        // 1, 2 or 4 (MT = 3 tiles of waves -> 4)
   const int MWp = MW == 3 ? 4 : MW;
-  const int PW = 4 / MWp;
-  const int mw = wave % MWp, pw = wave / MWp;
+  // KW waves split the K steps of every block (levels with few pixels and a long K: the workgroup's chain of dependent memory round
+  // trips shrinks KW-fold; their accumulators are summed through LDS, fixed order, before the epilogue)
+  const int KW = GX ? A.gx_kw : A.fw_kw;
+  const int PW = 4 / (MWp * KW);
+  const int mw = wave % MWp, kwi = (wave / MWp) % KW, pw = wave / (MWp * KW);
   constexpr int WPX = 16 * VEC;
   const int tps = GX ? A.gx_tiles_per_sample : A.tiles_per_sample;
   const int b = wg / tps, tile = wg - b * tps;
@@ -116,50 +124,130 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
       const int kn = min(KB, K - k0);
       const int ksteps = (kn + 3) >> 2;
       __syncthreads();                                          // previous block consumed (and s_kst written)
-      for (int idx = tid; idx < ksteps * mtn * 64; idx += kBlock) {
-        const int l = idx & 63, q = idx >> 6;
-        const int mt = q % mtn, ks = q / mtn;
-        const int out = (mt0 + mt) * 16 + (l & 15), kk = k0 + ks * 4 + (l >> 4);
-        float w = 0.f;
-        if (out < M && kk < k0 + kn) w = GX ? A.p.w1[static_cast<size_t>(kk) * g.C + out] : A.p.w1[static_cast<size_t>(out) * g.C + kk];
-        smem[idx] = w;
+      {
+        // source-major walk (coalesced reads of W1, scattered LDS writes into the A layout), SU loads in flight per thread
+        const int rowsb = mtn * 16, knp = ksteps * 4;
+        const int total = rowsb * knp;
+        constexpr int SU = 8;
+        for (int e0 = tid; e0 < total; e0 += kBlock * SU) {
+          float w[SU];
+#pragma unroll
+          for (int u = 0; u < SU; ++u) {
+            const int e = e0 + u * kBlock;
+            int ol, kq;
+            if (GX) { kq = e / rowsb; ol = e - kq * rowsb; }     // W1[kk][out]: contiguous in out
+            else { ol = e / knp; kq = e - ol * knp; }            // W1[out][kk]: contiguous in kk
+            const int out = mt0 * 16 + ol, kk = k0 + kq;
+            w[u] = 0.f;
+            if (e < total && out < M && kk < k0 + kn)
+              w[u] = GX ? A.p.w1[static_cast<size_t>(kk) * g.C + out] : A.p.w1[static_cast<size_t>(out) * g.C + kk];
+          }
+#pragma unroll
+          for (int u = 0; u < SU; ++u) {
+            const int e = e0 + u * kBlock;
+            if (e < total) {
+              int ol, kq;
+              if (GX) { kq = e / rowsb; ol = e - kq * rowsb; } else { ol = e / knp; kq = e - ol * knp; }
+              smem[((kq >> 2) * mtn + (ol >> 4)) * 64 + (kq & 3) * 16 + (ol & 15)] = w[u];
+            }
+          }
+        }
       }
       __syncthreads();
-      for (int ks = 0; ks < ksteps; ++ks) {
-        const int kk = k0 + ks * 4 + lk;                        // this lane's k channel
-        float bv[VEC];
+      // K steps in batches of KU: all of a batch's loads are issued before the first MFMA (a K step per memory round trip would make
+      // the workgroup a chain of C/4 dependent latencies: 64 of them at C = 256)
+      constexpr int KU = GX ? 4 : 8;
+      const int kper = (ksteps + KW - 1) / KW;                  // this wave's share of the block's K steps: [kwi*kper, ...)
+      const int kend = min(ksteps, (kwi + 1) * kper);
+      for (int ks0 = kwi * kper; ks0 < kend; ks0 += KU) {
+        float bv[KU][VEC], zq[GX ? KU : 1][VEC];
 #pragma unroll
-        for (int r = 0; r < VEC; ++r) bv[r] = 0.f;
-        if (px_ok && kk < k0 + kn) {
-          if (GX) {                                             // g_z = k_j (g_a - gbeta_j/n - zhat gamma'_j/n), zhat = (z - mean) rstd
-            float ga[VEC], zv[VEC];
-            load_vec<float, VEC>(gab + static_cast<size_t>(kk) * g.HW, ga);
-            load_vec<float, VEC>(zb + static_cast<size_t>(kk) * g.HW, zv);
-            const float kj = s_kst[kk], mean = s_kst[g.hidp + kk], rstd = s_kst[2 * g.hidp + kk];
-            const float gbn = s_kst[3 * g.hidp + kk], ggn = s_kst[4 * g.hidp + kk];
+        for (int u = 0; u < KU; ++u) {
+          const int kk = k0 + (ks0 + u) * 4 + lk;               // this lane's k channel
+          const bool ok = px_ok && (ks0 + u) < kend && kk < k0 + kn;
 #pragma unroll
-            for (int r = 0; r < VEC; ++r) bv[r] = kj * (ga[r] - gbn - (zv[r] - mean) * rstd * ggn);
-          } else {
-            load_vec<T, VEC>(xb + static_cast<size_t>(kk) * g.HW, bv);
+          for (int r = 0; r < VEC; ++r) bv[u][r] = 0.f;
+          if (GX) {
+#pragma unroll
+            for (int r = 0; r < VEC; ++r) zq[u][r] = 0.f;
+            if (ok) {
+              load_vec<float, VEC>(gab + static_cast<size_t>(kk) * g.HW, bv[u]);
+              load_vec<float, VEC>(zb + static_cast<size_t>(kk) * g.HW, zq[u]);
+            }
+          } else if (ok) {
+            load_vec<T, VEC>(xb + static_cast<size_t>(kk) * g.HW, bv[u]);
           }
         }
 #pragma unroll
-        for (int t = 0; t < kHeadMTW; ++t) {
-          const int mt = mw * kHeadMTW + t;
-          if (mt < mtn) {                                       // uniform per wave
-            const float a = smem[(ks * mtn + mt) * 64 + lane];
+        for (int u = 0; u < KU; ++u) {
+          const int ks = ks0 + u;
+          if (ks < kend) {                                      // uniform per wave
+            if (GX) {                                           // g_z = k_j (g_a - gbeta_j/n - zhat gamma'_j/n), zhat = (z - mean) rstd
+              const int kk = min(k0 + ks * 4 + lk, g.hidp - 1);
+              const float kj = s_kst[kk], mean = s_kst[g.hidp + kk], rstd = s_kst[2 * g.hidp + kk];
+              const float gbn = s_kst[3 * g.hidp + kk], ggn = s_kst[4 * g.hidp + kk];
 #pragma unroll
-            for (int r = 0; r < VEC; ++r) acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[r], acc[t][r], 0, 0, 0);
+              for (int r = 0; r < VEC; ++r) bv[u][r] = kj * (bv[u][r] - gbn - (zq[u][r] - mean) * rstd * ggn);
+              // (lanes whose load was skipped hold g_a = z = 0: their g_z is some finite number times a ZERO weight in A, or is
+              //  never stored -- except past H*W, where the result row is not stored either)
+            }
+#pragma unroll
+            for (int t = 0; t < kHeadMTW; ++t) {
+              const int mt = mw * kHeadMTW + t;
+              if (mt < mtn) {                                   // uniform per wave
+                const float a = smem[(ks * mtn + mt) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < VEC; ++r) acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[u][r], acc[t][r], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+    // ---- K split: sum the KW waves' accumulators (wave kwi = 0 keeps the result) ------------------------------------------------------
+    if (KW > 1) {
+#pragma unroll
+      for (int t = 0; t < kHeadMTW; ++t) {
+        __syncthreads();                                        // (first trip: the LDS block is consumed)
+        if (kwi > 0) {
+#pragma unroll
+          for (int r = 0; r < VEC; ++r)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) smem[((wave * VEC + r) * 4 + v) * 64 + lane] = acc[t][r][v];
+        }
+        __syncthreads();
+        if (kwi == 0) {
+          for (int q = 1; q < KW; ++q) {
+            const int ow = wave + q * MWp;                      // the wave with the same (mw, pw) and kwi = q
+#pragma unroll
+            for (int r = 0; r < VEC; ++r)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) acc[t][r][v] += smem[((ow * VEC + r) * 4 + v) * 64 + lane];
           }
         }
       }
     }
     // ---- epilogue of this M block -------------------------------------------------------------------------------------------
     if (!GX && g.training) __syncthreads();                     // LDS block consumed before s_sum (separate region, but keep waves together)
+    float oldv[GX ? kHeadMTW : 1][GX ? 4 : 1][VEC];             // GX + accumulate: every old value is requested before the first store
+    if (GX && A.accum_gx && kwi == 0) {
+#pragma unroll
+      for (int t = 0; t < kHeadMTW; ++t) {
+        const int mt = mw * kHeadMTW + t;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int out = (mt0 + mt) * 16 + lk * 4 + v;
+#pragma unroll
+          for (int r = 0; r < VEC; ++r) oldv[GX ? t : 0][GX ? v : 0][r] = 0.f;
+          if (mt < mtn && out < M && px_ok)
+            load_vec<T, VEC>(static_cast<const T*>(A.gx) + (static_cast<size_t>(b) * g.C + out) * g.HW + px, oldv[GX ? t : 0][GX ? v : 0]);
+        }
+      }
+    }
 #pragma unroll
     for (int t = 0; t < kHeadMTW; ++t) {
       const int mt = mw * kHeadMTW + t;
-      if (mt < mtn) {
+      if (mt < mtn && kwi == 0) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int out = (mt0 + mt) * 16 + lk * 4 + v;
@@ -171,7 +259,14 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
             s1 += ov[r]; s2 += ov[r] * ov[r];                    // pixels past H*W were loaded as zeros: they add nothing
           }
           if (out < M && px_ok) {
-            if (GX) store_vec_stream<T, VEC>(static_cast<T*>(A.gx) + (static_cast<size_t>(b) * g.C + out) * g.HW + px, ov, true);
+            if (GX) {
+              T* gp = static_cast<T*>(A.gx) + (static_cast<size_t>(b) * g.C + out) * g.HW + px;
+              if (A.accum_gx) {                                  // the feature's other consumer (MaskCBAM) already left its gradient here
+#pragma unroll
+                for (int r = 0; r < VEC; ++r) ov[r] += oldv[GX ? t : 0][GX ? v : 0][r];
+              }
+              store_vec_stream<T, VEC>(gp, ov, true);
+            }
             else store_vec<float, VEC>(A.c.z + (static_cast<size_t>(b) * g.hid + out) * g.HW + px, ov);
           }
           if (!GX && g.training) {
@@ -208,95 +303,148 @@ __global__ __launch_bounds__(kBlock) void k_head_gemm(const Group<HeadArgs> G) {
 //   running estimate, momentum m).  Eval mode: mean / rstd from the running statistics.  Workgroup = 8 channels (16 sums) x 16 strides.
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_head_stats(const Group<HeadArgs> G) {
-  __shared__ double red[16][17];
+  __shared__ double red[kBlock];
   int local;
   const int l = find_level(G, blockIdx.x, local);
   const HeadArgs& A = G.lv[l];
   const HeadGeo& g = A.g;
-  const int tid = threadIdx.x, s = tid & 15, gq = tid >> 4;
-  const int j0 = local * 8;
-  const int j = j0 + (s >> 1), which = s & 1;                   // sum index s = 2*(j - j0) + {0: z, 1: z^2}
+  const int tid = threadIdx.x, which = tid & 1, gq = tid >> 1;  // workgroup = one hidden channel: 2 sums x 128 strides over the tiles
+  const int j = local;
   double acc = 0.0;
-  if (g.training && j < g.hid) {
-    for (int w = gq; w < A.nwg; w += 16) acc += static_cast<double>(A.c.part[(static_cast<size_t>(w) * 2 + which) * g.hidp + j]);
-  }
-  red[gq][s] = acc;
-  __syncthreads();
-  if (tid < 8) {
-    const int jj = j0 + tid;
-    if (jj < g.hid) {
-      float mean, var;
-      if (g.training) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int q = 0; q < 16; ++q) { s1 += red[q][2 * tid]; s2 += red[q][2 * tid + 1]; }
-        const double n = static_cast<double>(g.B) * g.HW;
-        const double m = s1 / n;
-        double v = s2 / n - m * m;
-        if (v < 0.0) v = 0.0;
-        mean = static_cast<float>(m); var = static_cast<float>(v);
-        const double unb = n > 1.0 ? v * n / (n - 1.0) : v;
-        A.p.rmean[jj] = (1.f - g.momentum) * A.p.rmean[jj] + g.momentum * mean;
-        A.p.rvar[jj] = (1.f - g.momentum) * A.p.rvar[jj] + g.momentum * static_cast<float>(unb);
-      } else {
-        mean = A.p.rmean[jj]; var = A.p.rvar[jj];
-      }
-      A.c.mean[jj] = mean;
-      A.c.rstd[jj] = 1.0f / sqrtf(var + g.eps);
+  if (g.training) {
+    const float* p = A.c.part + static_cast<size_t>(which) * g.hidp + j;
+    constexpr int U = 4;
+    int w = gq;
+    for (; w + (U - 1) * 128 < A.nwg; w += U * 128) {           // U independent loads in flight
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = p[static_cast<size_t>(w + u * 128) * 2 * g.hidp];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += static_cast<double>(v[u]);
     }
-    if (g.training && local == 0 && tid == 0 && A.p.nbt) *A.p.nbt += 1;
+    for (; w < A.nwg; w += 128) acc += static_cast<double>(p[static_cast<size_t>(w) * 2 * g.hidp]);
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int o = kBlock >> 1; o >= 2; o >>= 1) {                  // fixed-order tree; the two sums stay on even / odd slots
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float mean, var;
+    if (g.training) {
+      const double n = static_cast<double>(g.B) * g.HW;
+      const double m = red[0] / n;
+      double v = red[1] / n - m * m;
+      if (v < 0.0) v = 0.0;
+      mean = static_cast<float>(m); var = static_cast<float>(v);
+      const double unb = n > 1.0 ? v * n / (n - 1.0) : v;
+      A.p.rmean[j] = (1.f - g.momentum) * A.p.rmean[j] + g.momentum * mean;
+      A.p.rvar[j] = (1.f - g.momentum) * A.p.rvar[j] + g.momentum * static_cast<float>(unb);
+      if (j == 0 && A.p.nbt) *A.p.nbt += 1;
+    } else {
+      mean = A.p.rmean[j]; var = A.p.rvar[j];
+    }
+    const float rstd = 1.0f / sqrtf(var + g.eps);
+    A.c.mean[j] = mean;
+    A.c.rstd[j] = rstd;
+    float* par = A.c.par + static_cast<size_t>(j) * kHeadPar;
+    const float sc = A.p.gamma[j] * rstd;
+    par[0] = sc; par[1] = A.p.beta[j] - mean * sc; par[2] = mean; par[3] = rstd;
+    for (int q = 0; q < 9; ++q) par[4 + q] = A.p.wh[static_cast<size_t>(j) * 9 + q];
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_head_out: logits = conv3x3(SiLU(gamma * zhat + beta)) + bias                                  segmentation.py:83-92
-//   workgroup = 16 x 16 pixels of one sample, one pixel per thread; the activations of kHeadJC channels with a 1-px halo are staged
-//   in LDS per pass (zero padding outside the image), the 3x3 weights of the pass beside them.
+//   workgroup = a run of kHeadOutPx = 256 consecutive pixels of one sample (H*W flattened: full lanes whatever the image shape); its
+//   4 waves cover the SAME pixels (lane = 4 consecutive ones) and split the hidden channels 4 ways, so a level with many channels and
+//   few pixels (P5) still has a short chain per workgroup; the four partial sums meet in LDS.  Per pass a wave stages the activations
+//   of kHeadJO of its channels over the run plus W+1 pixels either side (zero outside the sample = the conv's zero padding in y), reads
+//   6 consecutive values per channel and window row for its 4 outputs and masks the taps that would wrap around a row end (padding
+//   in x).  3x3 weights and BatchNorm constants come from the per-channel table with scalar loads.
 // ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kHeadOutPx = 256;
+constexpr int kHeadJO = 4;
 template <typename T>
 __device__ __forceinline__ void head_out_body(const HeadArgs& A, const int wg, float* smem) {
   const HeadGeo& g = A.g;
-  const int tid = threadIdx.x;
-  constexpr int TS = kHeadT2, PS = TS + 2;
-  const int per = A.t2x * A.t2y;
-  const int b = wg / per, tt = wg - b * per;
-  const int y0 = (tt / A.t2x) * TS, x0 = (tt % A.t2x) * TS;
-  const int ty = tid / TS, tx = tid - ty * TS;
-  float* s_act = smem;                                          // [JC][PS][PS]
-  float* s_w = smem + kHeadJC * PS * PS;                        // [JC][9]
-  float* s_bn = s_w + kHeadJC * 9;                              // [JC][2]: scale = gamma*rstd, shift = beta - mean*scale
-  float acc = 0.f;
-  for (int j0 = 0; j0 < g.hid; j0 += kHeadJC) {
-    const int jn = min(kHeadJC, g.hid - j0);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int per = (g.HW + kHeadOutPx - 1) / kHeadOutPx;
+  const int b = wg / per, p0 = (wg - b * per) * kHeadOutPx;
+  const int halo = g.W + 1, HL = kHeadOutPx + 2 * halo;
+  const int pt = p0 + 4 * lane;                                 // this lane's first pixel
+  float ml[4], mr[4];                                           // 0 where the left / right tap would wrap around the row end
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int x = (pt + i) % g.W;
+    ml[i] = x > 0 ? 1.f : 0.f; mr[i] = x < g.W - 1 ? 1.f : 0.f;
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* zb = A.c.z + static_cast<size_t>(b) * g.hid * g.HW;
+  float* s_w = smem + static_cast<size_t>(wave) * kHeadJO * A.out_hl_max;    // this wave's staging area
+  const int cw = (g.hid + 3) >> 2;                              // channels per wave
+  const int jlo = wave * cw, jhi = min(g.hid, jlo + cw);
+  const int npass = (cw + kHeadJO - 1) / kHeadJO;               // uniform over the workgroup
+  for (int ps = 0; ps < npass; ++ps) {
+    const int j0 = jlo + ps * kHeadJO;
+    const int jn = max(0, min(kHeadJO, jhi - j0));
+    const float* par0 = A.c.par + static_cast<size_t>(min(j0, g.hid - 1)) * kHeadPar;   // uniform per wave: scalar loads
     __syncthreads();
-    for (int i = tid; i < jn * 9; i += kBlock) s_w[i] = A.p.wh[static_cast<size_t>(j0) * 9 + i];
-    if (tid < jn) {
-      const float sc = A.p.gamma[j0 + tid] * A.c.rstd[j0 + tid];
-      s_bn[2 * tid] = sc; s_bn[2 * tid + 1] = A.p.beta[j0 + tid] - A.c.mean[j0 + tid] * sc;
-    }
-    __syncthreads();
-    for (int i = tid; i < jn * PS * PS; i += kBlock) {
-      const int jj = i / (PS * PS), r = i - jj * PS * PS;
-      const int yy = y0 + r / PS - 1, xx = x0 + r % PS - 1;
-      float sv = 0.f;
-      if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) {
-        const float z = A.c.z[(static_cast<size_t>(b) * g.hid + j0 + jj) * g.HW + yy * g.W + xx];
-        sv = siluf(z * s_bn[2 * jj] + s_bn[2 * jj + 1]);
+    const int total = jn * HL;
+    constexpr int SU = 14;                                      // loads in flight per lane while staging
+    for (int e0 = lane; e0 < total; e0 += kWave * SU) {
+      float zv[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int e = e0 + u * kWave;
+        const int jj = e / HL, r = e - jj * HL;
+        const int p = p0 - halo + r;
+        zv[u] = 0.f;
+        if (e < total && p >= 0 && p < g.HW) zv[u] = zb[static_cast<size_t>(j0 + jj) * g.HW + p];
       }
-      s_act[i] = sv;
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int e = e0 + u * kWave;
+        if (e < total) {
+          const int jj = e / HL, r = e - jj * HL;
+          const int p = p0 - halo + r;
+          s_w[e] = (p >= 0 && p < g.HW) ? siluf(zv[u] * par0[jj * kHeadPar] + par0[jj * kHeadPar + 1]) : 0.f;
+        }
+      }
     }
     __syncthreads();
     for (int jj = 0; jj < jn; ++jj) {
-      const float* a = s_act + jj * PS * PS + ty * PS + tx;
-      const float* w = s_w + jj * 9;
+      const float* w = par0 + jj * kHeadPar + 4;                 // SGPR operands
+      const float* a = s_w + jj * HL + 4 * lane + halo;          // activation of pixel pt
 #pragma unroll
-      for (int u = 0; u < 3; ++u)
+      for (int u = 0; u < 3; ++u) {
+        const float* row = a + (u - 1) * g.W - 1;
+        float s6[6];
 #pragma unroll
-        for (int v = 0; v < 3; ++v) acc += w[u * 3 + v] * a[u * PS + v];
+        for (int q = 0; q < 6; ++q) s6[q] = row[q];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[i] += w[u * 3] * (ml[i] * s6[i]) + w[u * 3 + 1] * s6[i + 1] + w[u * 3 + 2] * (mr[i] * s6[i + 2]);
+      }
     }
   }
-  const int y = y0 + ty, x = x0 + tx;
-  if (y < g.H && x < g.W)
-    static_cast<T*>(A.logits)[static_cast<size_t>(b) * g.HW + y * g.W + x] = from_f32<T>(acc + A.p.bh[0]);
+  __syncthreads();                                              // the waves' channel shares meet (fixed order)
+  float* s_acc = smem;
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_acc[(wave * 4 + i) * kWave + lane] = acc[i];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float bias = A.p.bh[0];
+    T* lo = static_cast<T*>(A.logits) + static_cast<size_t>(b) * g.HW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = ((acc[i] + s_acc[(4 + i) * kWave + lane]) + (s_acc[(8 + i) * kWave + lane] + s_acc[(12 + i) * kWave + lane])) + bias;
+      if (pt + i < g.HW) lo[pt + i] = from_f32<T>(v);
+    }
+  }
 }
 
 template <typename T>
@@ -310,72 +458,108 @@ __global__ __launch_bounds__(kBlock) void k_head_out(const Group<HeadArgs> G) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_head_bwd_act: g_s = convT3x3(g_logits, W_h);  g_a = g_s * SiLU'(a)  (stored);  per tile and hidden channel the partial sums
 //   [0] sum g_a   [1] sum g_a*zhat   [2..10] dW_h taps: sum s(y,x) * g(y-u+1, x-v+1)   [11] sum g (channel 0 only: db_h)
-//   Same 16 x 16 tiling; g_logits with its halo in LDS, each thread keeps its 9 neighbours in registers for all channels.
+//   workgroup = (run of 256*ppt consecutive pixels of one sample, group of kHeadJC hidden channels); thread = ppt pixels 256 apart
+//   (ppt = 4 / 2 / 1 by image size: the 12 wave reductions per channel are paid once for ppt pixels).  g_logits of the run plus W+1
+//   pixels either side in LDS; every thread keeps the 9 neighbours of each of its pixels in registers for all channels (taps that would
+//   wrap around a row end are zeroed).
 // ---------------------------------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void head_bwd_act_body(const HeadArgs& A, const int wg, float* smem) {
+__device__ __forceinline__ void head_bwd_act_body(const HeadArgs& A, const int wgl, float* smem) {
   const HeadGeo& g = A.g;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  constexpr int TS = kHeadT2, PS = TS + 2;
-  const int per = A.t2x * A.t2y;
-  const int b = wg / per, tt = wg - b * per;
-  const int y0 = (tt / A.t2x) * TS, x0 = (tt % A.t2x) * TS;
-  const int ty = tid / TS, tx = tid - ty * TS;
-  float* s_g = smem;                                            // [PS][PS]
-  float* s_red = smem + PS * PS;                                // [4 waves][kHeadJC][kHeadNStat]
+  constexpr int PP = 4;                                         // upper bound of pixels per thread
+  constexpr int ZU = kHeadJC;                                   // the workgroup's channels: their z values are requested together (x ppt pixels)
+  const int ppt = A.act_ppt, TP = kBlock * ppt;
+  const int ncg = (g.hid + kHeadJC - 1) / kHeadJC;
+  const int wg = wgl / ncg, cgq = wgl - wg * ncg;
+  const int jlo = cgq * kHeadJC, jhi = min(g.hid, jlo + kHeadJC);
+  const int per = (g.HW + TP - 1) / TP;
+  const int b = wg / per, p0 = (wg - b * per) * TP;
+  const int halo = g.W + 1, HL = TP + 2 * halo;
+  float* s_g = smem;                                            // [HL]
+  float* s_red = smem + A.act_hl_max;                           // [4 waves][ZU][kHeadNStat], behind the longest run of the launch
   const T* gl = static_cast<const T*>(A.gl) + static_cast<size_t>(b) * g.HW;
-  for (int i = tid; i < PS * PS; i += kBlock) {
-    const int yy = y0 + i / PS - 1, xx = x0 + i % PS - 1;
-    s_g[i] = (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) ? to_f32<T>(gl[yy * g.W + xx]) : 0.f;
+  const float* gl2 = A.gl2 ? A.gl2 + static_cast<size_t>(b) * g.HW : nullptr;
+  for (int i = tid; i < HL; i += kBlock) {
+    const int p = p0 - halo + i;
+    float v = 0.f;
+    if (p >= 0 && p < g.HW) {
+      v = to_f32<T>(gl[p]);
+      if (gl2) v += gl2[p];                                     // the logits' second consumer (MaskCBAM's dL/dmask beside the loss's gradient)
+    }
+    s_g[i] = v;
   }
   __syncthreads();
-  float g9[9];                                                  // g9[u*3+v] = g(y-u+1, x-v+1)
+  float g9[PP][9];                                              // g9[i][u*3+v] = g(y-u+1, x-v+1) of pixel i
+  bool in[PP];
 #pragma unroll
-  for (int u = 0; u < 3; ++u)
+  for (int i = 0; i < PP; ++i) {
+    const int p = p0 + tid + i * kBlock;
+    in[i] = i < ppt && p < g.HW;
+    const int x = p % g.W;
+    const float m_lo = x > 0 ? 1.f : 0.f, m_hi = x < g.W - 1 ? 1.f : 0.f;   // g(.., x-1) / g(.., x+1) exist
+    const float* c = s_g + (i < ppt ? tid + i * kBlock : tid) + halo;
 #pragma unroll
-    for (int v = 0; v < 3; ++v) g9[u * 3 + v] = s_g[(ty + 2 - u) * PS + (tx + 2 - v)];
-  const int y = y0 + ty, x = x0 + tx;
-  const bool in = y < g.H && x < g.W;
-  const size_t po = static_cast<size_t>(in ? y * g.W + x : 0);
+    for (int u = 0; u < 3; ++u) {
+      const float* row = c + (1 - u) * g.W;                     // row y - u + 1
+      g9[i][u * 3 + 0] = m_hi * row[1];                          // v = 0: x + 1
+      g9[i][u * 3 + 1] = row[0];
+      g9[i][u * 3 + 2] = m_lo * row[-1];                         // v = 2: x - 1
+    }
+  }
   float* part = A.s.part1 + static_cast<size_t>(wg) * g.hidp * kHeadNStat;
-  for (int j0 = 0; j0 < g.hid; j0 += kHeadJC) {
-    const int jn = min(kHeadJC, g.hid - j0);
-    for (int jj = 0; jj < jn; ++jj) {
-      const int j = j0 + jj;
-      float r[kHeadNStat];
+  const float* zb = A.c.z + static_cast<size_t>(b) * g.hid * g.HW;
+  float* gab = A.s.ga + static_cast<size_t>(b) * g.hid * g.HW;
+  for (int j0 = jlo; j0 < jhi; j0 += ZU) {
+    const int jn = min(ZU, jhi - j0);
+    float zq[ZU][PP];
 #pragma unroll
-      for (int q = 0; q < kHeadNStat; ++q) r[q] = 0.f;
-      if (in) {
-        const size_t o = (static_cast<size_t>(b) * g.hid + j) * g.HW + po;
-        const float z = A.c.z[o];
-        const float rstd = A.c.rstd[j];
-        const float zh = (z - A.c.mean[j]) * rstd;
-        const float a = zh * A.p.gamma[j] + A.p.beta[j];
-        const float sg = 1.f / (1.f + expf(-a));
-        const float sv = a * sg;
-        const float* w = A.p.wh + static_cast<size_t>(j) * 9;
-        float gs = 0.f;
+    for (int jj = 0; jj < ZU; ++jj)
 #pragma unroll
-        for (int q = 0; q < 9; ++q) gs += w[q] * g9[q];
-        const float ga = gs * (sg * (1.f + a * (1.f - sg)));
-        A.s.ga[o] = ga;
-        r[0] = ga; r[1] = ga * zh;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) r[2 + q] = sv * g9[q];
-        r[11] = j == 0 ? g9[4] : 0.f;
+      for (int i = 0; i < PP; ++i) {
+        zq[jj][i] = 0.f;
+        if (jj < jn && in[i]) zq[jj][i] = zb[static_cast<size_t>(j0 + jj) * g.HW + p0 + tid + i * kBlock];
       }
 #pragma unroll
-      for (int q = 0; q < kHeadNStat; ++q) r[q] = wave_group_sum(r[q], kWave);
-      if (lane == 0) {
+    for (int jj = 0; jj < ZU; ++jj) {
+      if (jj < jn) {                                            // uniform
+        const int j = j0 + jj;
+        const float* pr = A.c.par + static_cast<size_t>(j) * kHeadPar;   // uniform address: scalar loads, SGPR operands
+        float r[kHeadNStat];
 #pragma unroll
-        for (int q = 0; q < kHeadNStat; ++q) s_red[(wave * kHeadJC + jj) * kHeadNStat + q] = r[q];
+        for (int q = 0; q < kHeadNStat; ++q) r[q] = 0.f;
+#pragma unroll
+        for (int i = 0; i < PP; ++i) {
+          if (in[i]) {
+            const float z = zq[jj][i];
+            const float zh = (z - pr[2]) * pr[3];
+            const float a = z * pr[0] + pr[1];
+            const float sg = 1.f / (1.f + expf(-a));
+            const float sv = a * sg;
+            float gs = 0.f;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) gs += pr[4 + q] * g9[i][q];
+            const float ga = gs * (sg * (1.f + a * (1.f - sg)));
+            gab[static_cast<size_t>(j) * g.HW + p0 + tid + i * kBlock] = ga;
+            r[0] += ga; r[1] += ga * zh;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) r[2 + q] += sv * g9[i][q];
+            if (j == 0) r[11] += g9[i][4];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < kHeadNStat; ++q) r[q] = wave_group_sum(r[q], kWave);
+        if (lane == 0) {
+#pragma unroll
+          for (int q = 0; q < kHeadNStat; ++q) s_red[(wave * ZU + jj) * kHeadNStat + q] = r[q];
+        }
       }
     }
     __syncthreads();
     for (int i = tid; i < jn * kHeadNStat; i += kBlock) {
-      float s = 0.f;
-      for (int w = 0; w < 4; ++w) s += s_red[w * kHeadJC * kHeadNStat + i];
-      part[static_cast<size_t>(j0) * kHeadNStat + i] = s;
+      float sum = 0.f;
+      for (int w = 0; w < 4; ++w) sum += s_red[w * ZU * kHeadNStat + i];
+      part[static_cast<size_t>(j0) * kHeadNStat + i] = sum;
     }
     __syncthreads();
   }
@@ -400,8 +584,20 @@ __global__ __launch_bounds__(kBlock) void k_head_bwd_fin(const Group<HeadArgs> G
   const int tid = threadIdx.x, s = tid & 15, gq = tid >> 4;
   const int j = local;
   double acc = 0.0;
-  if (s < kHeadNStat)
-    for (int w = gq; w < A.nwg1; w += 16) acc += static_cast<double>(A.s.part1[(static_cast<size_t>(w) * g.hidp + j) * kHeadNStat + s]);
+  if (s < kHeadNStat) {
+    const float* p = A.s.part1 + static_cast<size_t>(j) * kHeadNStat + s;
+    const size_t stride = static_cast<size_t>(g.hidp) * kHeadNStat;
+    constexpr int U = 8;
+    int w = gq;
+    for (; w + (U - 1) * 16 < A.nwg1; w += U * 16) {            // U independent loads in flight
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = p[(w + u * 16) * stride];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += static_cast<double>(v[u]);
+    }
+    for (; w < A.nwg1; w += 16) acc += static_cast<double>(p[w * stride]);
+  }
   red[gq][s] = acc;
   __syncthreads();
   if (tid < kHeadNStat) {
@@ -433,7 +629,7 @@ __global__ __launch_bounds__(kBlock) void k_head_bwd_fin(const Group<HeadArgs> G
 // k_head_bwd_gw: dW1[j,c] = sum_{b,px} g_z[b,j,px] x[b,c,px]      (M = hid, N = C, K = pixels)
 //   A = g_z (lane l: hidden channel l%16 of its tile, pixel slot l/16), B = x (lane l: pixel slot l/16, channel l%16 of its tile): both are
 //   "16 channels x 16 pixels" loads (16 B per lane with VEC = 4: register r = pixel 4*(l/16)+r of the 16; K sub-step r uses register r
-//   of both operands).  Workgroup = (channel block of kHeadCB channels, one of kHeadGwWG pixel shares); its 4 waves take different
+//   of both operands).  Workgroup = (channel block of kHeadCB channels, one of nshare pixel shares); its 4 waves take different
 //   16*VEC... pixel chunks, accumulate all (hid tile, channel tile) products of the block and are summed through LDS at the end.
 //   Accumulators: MTB x 4 tiles per wave (MTB = min(MT, 4): hid > 64 runs in passes of 64 hidden channels, re-reading x).
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -442,7 +638,7 @@ __device__ __forceinline__ void head_bwd_gw_body(const HeadArgs& A, const int wg
   const HeadGeo& g = A.g;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lq = lane >> 4;
-  const int cb = wg / kHeadGwWG, share = wg - cb * kHeadGwWG;
+  const int cb = wg / A.nshare, share = wg - cb * A.nshare;
   const int c0 = cb * kHeadCB;
   const int MT = g.hidp >> 4;
   constexpr int NT = kHeadCB / 16;
@@ -467,40 +663,51 @@ __device__ __forceinline__ void head_bwd_gw_body(const HeadArgs& A, const int wg
       const int j = min((mt0 + t) * 16 + lr, g.hidp - 1);
       kj[t] = s_kst[j]; mean[t] = s_kst[g.hidp + j]; rstd[t] = s_kst[2 * g.hidp + j]; gbn[t] = s_kst[3 * g.hidp + j]; ggn[t] = s_kst[4 * g.hidp + j];
     }
-    for (long long ch = static_cast<long long>(share) * 4 + wave; ch < total; ch += 4ll * kHeadGwWG) {
-      const int b = static_cast<int>(ch / nch);
-      const int px = (static_cast<int>(ch - static_cast<long long>(b) * nch)) * CHP + lq * VEC;
-      const bool ok = px < g.HW;
-      const size_t pxo = ok ? px : 0;
-      float av[kHeadMTW][VEC], bv[NT][VEC];
+    // two pixel chunks per trip: both chunks' loads are issued before the first MFMA (a chunk per memory round trip would leave each
+    // wave a chain of dependent latencies)
+    const long long stride = 4ll * A.nshare;
+    for (long long ch0 = static_cast<long long>(share) * 4 + wave; ch0 < total; ch0 += 2 * stride) {
+      float av[2][kHeadMTW][VEC], bv[2][NT][VEC];
 #pragma unroll
-      for (int t = 0; t < kHeadMTW; ++t) {
-        const int j = (mt0 + t) * 16 + lr;
+      for (int h = 0; h < 2; ++h) {
+        const long long ch = ch0 + h * stride;
+        const bool live = ch < total;
+        const int b = live ? static_cast<int>(ch / nch) : 0;
+        const int px = live ? (static_cast<int>(ch - static_cast<long long>(b) * nch)) * CHP + lq * VEC : g.HW;
+        const bool ok = px < g.HW;
+        const size_t pxo = ok ? px : 0;
 #pragma unroll
-        for (int r = 0; r < VEC; ++r) av[t][r] = 0.f;
-        if (t < mtn && ok && j < g.hid) {
-          float ga[VEC], zv[VEC];
-          const size_t o = (static_cast<size_t>(b) * g.hid + j) * g.HW + pxo;
-          load_vec<float, VEC>(A.s.ga + o, ga);
-          load_vec<float, VEC>(A.c.z + o, zv);
+        for (int t = 0; t < kHeadMTW; ++t) {
+          const int j = (mt0 + t) * 16 + lr;
 #pragma unroll
-          for (int r = 0; r < VEC; ++r) av[t][r] = kj[t] * (ga[r] - gbn[t] - (zv[r] - mean[t]) * rstd[t] * ggn[t]);
+          for (int r = 0; r < VEC; ++r) av[h][t][r] = 0.f;
+          if (t < mtn && ok && j < g.hid) {
+            float ga[VEC], zv[VEC];
+            const size_t o = (static_cast<size_t>(b) * g.hid + j) * g.HW + pxo;
+            load_vec<float, VEC>(A.s.ga + o, ga);
+            load_vec<float, VEC>(A.c.z + o, zv);
+#pragma unroll
+            for (int r = 0; r < VEC; ++r) av[h][t][r] = kj[t] * (ga[r] - gbn[t] - (zv[r] - mean[t]) * rstd[t] * ggn[t]);
+          }
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int c = c0 + n * 16 + lr;
+#pragma unroll
+          for (int r = 0; r < VEC; ++r) bv[h][n][r] = 0.f;
+          if (ok && c < g.C) load_vec<T, VEC>(static_cast<const T*>(A.x) + (static_cast<size_t>(b) * g.C + c) * g.HW + pxo, bv[h][n]);
         }
       }
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int c = c0 + n * 16 + lr;
+      for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int r = 0; r < VEC; ++r) bv[n][r] = 0.f;
-        if (ok && c < g.C) load_vec<T, VEC>(static_cast<const T*>(A.x) + (static_cast<size_t>(b) * g.C + c) * g.HW + pxo, bv[n]);
-      }
+        for (int t = 0; t < kHeadMTW; ++t) {
+          if (t < mtn) {
 #pragma unroll
-      for (int t = 0; t < kHeadMTW; ++t) {
-        if (t < mtn) {
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
-          for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < VEC; ++r) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][r], bv[n][r], acc[t][n], 0, 0, 0);
+              for (int r = 0; r < VEC; ++r) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][t][r], bv[h][n][r], acc[t][n], 0, 0, 0);
+          }
         }
       }
     }
@@ -530,21 +737,36 @@ __global__ __launch_bounds__(kBlock) void k_head_bwd_gw(const Group<HeadArgs> G)
   head_bwd_gw_body<T, VEC>(G.lv[l], local, smem);
 }
 
-// k_head_bwd_gwf: dW1[j,c] = sum over the kHeadGwWG pixel shares (fixed order)
+// k_head_bwd_gwf: dW1[j,c] = sum over the pixel shares: workgroup = 64 outputs x 4 share strides (8 loads in flight each), then a
+//   fixed-order combine through LDS
 __global__ __launch_bounds__(kBlock) void k_head_bwd_gwf(const Group<HeadArgs> G) {
+  __shared__ float red[kBlock];
   int local;
   const int l = find_level(G, blockIdx.x, local);
   const HeadArgs& A = G.lv[l];
   const HeadGeo& g = A.g;
-  const int idx = local * kBlock + threadIdx.x;
-  if (idx >= g.hid * g.C) return;
-  const int j = idx / g.C, c = idx - j * g.C;
-  const int cb = c / kHeadCB, cc = c - cb * kHeadCB;
-  const float* p = A.s.gwpart + (static_cast<size_t>(cb) * kHeadGwWG * g.hidp + j) * kHeadCB + cc;
+  const int tid = threadIdx.x, o = tid & 63, q = tid >> 6;
+  const int idx = local * 64 + o;
   float s = 0.f;
-#pragma unroll 8
-  for (int w = 0; w < kHeadGwWG; ++w) s += p[static_cast<size_t>(w) * g.hidp * kHeadCB];
-  A.gw1[idx] = s;
+  if (idx < g.hid * g.C) {
+    const int j = idx / g.C, c = idx - j * g.C;
+    const int cb = c / kHeadCB, cc = c - cb * kHeadCB;
+    const float* p = A.s.gwpart + (static_cast<size_t>(cb) * A.nshare * g.hidp + j) * kHeadCB + cc;
+    const size_t stride = static_cast<size_t>(g.hidp) * kHeadCB;
+    constexpr int U = 8;
+    int w = q;
+    for (; w + (U - 1) * 4 < A.nshare; w += U * 4) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = p[(w + u * 4) * stride];
+#pragma unroll
+      for (int u = 0; u < U; ++u) s += v[u];
+    }
+    for (; w < A.nshare; w += 4) s += p[w * stride];
+  }
+  red[tid] = s;
+  __syncthreads();
+  if (q == 0 && idx < g.hid * g.C) A.gw1[idx] = (red[o] + red[64 + o]) + (red[128 + o] + red[192 + o]);
 }
 
 }  // namespace mgacbam

@@ -1011,28 +1011,43 @@ static int head_check_shape(int B, int C, int H, int W, int hidden) {
     return fail(MGACBAM_E_SHAPE, "mask head: tensor too large B=%d C=%d H=%d W=%d", B, C, H, W);
   return 0;
 }
-struct HeadTiling { int vec, hidp, cp, tile_px, tps, nwg, gx_tile_px, gx_tps, t2x, t2y, nwg1, ncb; };
-static int head_pw(int mtiles) {                                 // waves along pixels of k_head_gemm for `mtiles` 16-output tiles (head.cuh)
+struct HeadTiling { int vec, hidp, cp, tile_px, tps, nwg, gx_tile_px, gx_tps, fw_kw, gx_kw, nwg_out, nwg1, act_ppt, act_hl, ncb, nshare; };
+// wave arrangement of k_head_gemm (head.cuh): MW waves along M for `mtiles` 16-output tiles, KW waves along K when K is long (a chain of
+// K/4 dependent steps otherwise), the rest along pixels
+static void head_waves(int mtiles, int K, int& pw, int& kw) {
   int mw = std::min(4, (mtiles + kHeadMTW - 1) / kHeadMTW);
   if (mw == 3) mw = 4;
-  return 4 / mw;
+  const int rest = 4 / mw;
+  kw = K >= 128 ? rest : 1;
+  pw = rest / kw;
 }
 static HeadTiling head_tiling(int B, int C, int H, int W, int hidden) {
   HeadTiling t;
   const int HW = H * W;
   t.vec = (HW % 4 == 0) ? 4 : 1;
   t.hidp = (hidden + 15) & ~15; t.cp = (C + 15) & ~15;
-  t.tile_px = head_pw(t.hidp / 16) * 16 * t.vec;
+  int pw;
+  head_waves(t.hidp / 16, C, pw, t.fw_kw);
+  t.tile_px = pw * 16 * t.vec;
   t.tps = (HW + t.tile_px - 1) / t.tile_px;
   t.nwg = B * t.tps;
-  t.gx_tile_px = head_pw(t.cp / 16) * 16 * t.vec;
+  head_waves(t.cp / 16, hidden, pw, t.gx_kw);
+  t.gx_tile_px = pw * 16 * t.vec;
   t.gx_tps = (HW + t.gx_tile_px - 1) / t.gx_tile_px;
-  t.t2x = (W + kHeadT2 - 1) / kHeadT2; t.t2y = (H + kHeadT2 - 1) / kHeadT2;
-  t.nwg1 = B * t.t2x * t.t2y;
+  t.nwg_out = B * ((HW + kHeadOutPx - 1) / kHeadOutPx);
+  t.act_ppt = HW >= 2048 ? 4 : (HW >= 512 ? 2 : 1);             // pixels per thread of k_head_bwd_act (amortises its per-channel reductions)
+  t.nwg1 = B * ((HW + kBlock * t.act_ppt - 1) / (kBlock * t.act_ppt));
+  t.act_hl = kBlock * t.act_ppt + 2 * (W + 1);
   t.ncb = (C + kHeadCB - 1) / kHeadCB;
+  // pixel shares of k_head_bwd_gw: as many workgroups as ~4 MB of dW1 partials allow (32..256), and no more than there are pairs of pixel chunks
+  const long long per_share = static_cast<long long>(t.ncb) * t.hidp * kHeadCB * 4;
+  long long ns = (4ll << 20) / per_share;
+  const long long chunks = static_cast<long long>(B) * ((HW + 4 * t.vec - 1) / (4 * t.vec));
+  ns = std::min(ns, (chunks + 7) / 8);
+  t.nshare = static_cast<int>(std::max(32ll, std::min(256ll, ns)));
   return t;
 }
-struct HeadCtxLayout { size_t z, mean, rstd, part, total; };
+struct HeadCtxLayout { size_t z, mean, rstd, par, part, total; };
 static HeadCtxLayout head_ctx_layout(int B, int C, int H, int W, int hidden) {
   const HeadTiling t = head_tiling(B, C, H, W, hidden);
   HeadCtxLayout L;
@@ -1040,6 +1055,7 @@ static HeadCtxLayout head_ctx_layout(int B, int C, int H, int W, int hidden) {
   auto take = [&](size_t n) { size_t at = o; o = align16(o + n * 4); return at; };
   L.z = take(static_cast<size_t>(B) * hidden * H * W);
   L.mean = take(t.hidp); L.rstd = take(t.hidp);
+  L.par = take(static_cast<size_t>(t.hidp) * kHeadPar);
   L.part = take(static_cast<size_t>(t.nwg) * 2 * t.hidp);
   L.total = o;
   return L;
@@ -1053,7 +1069,7 @@ static HeadScratchLayout head_scratch_layout(int B, int C, int H, int W, int hid
   L.ga = take(static_cast<size_t>(B) * hidden * H * W);
   L.part1 = take(static_cast<size_t>(t.nwg1) * t.hidp * kHeadNStat);
   L.kst = take(5 * static_cast<size_t>(t.hidp));
-  L.gwpart = take(static_cast<size_t>(t.ncb) * kHeadGwWG * t.hidp * kHeadCB);
+  L.gwpart = take(static_cast<size_t>(t.ncb) * t.nshare * t.hidp * kHeadCB);
   L.total = o;
   return L;
 }
@@ -1079,10 +1095,10 @@ static int head_common(const mgahead_params_t& P, int B, int C, int H, int W, in
   const HeadCtxLayout L = head_ctx_layout(B, C, H, W, P.hidden);
   char* cp = static_cast<char*>(ctx);
   A.c = HeadCtx{reinterpret_cast<float*>(cp + L.z), reinterpret_cast<float*>(cp + L.mean), reinterpret_cast<float*>(cp + L.rstd),
-                reinterpret_cast<float*>(cp + L.part)};
+                reinterpret_cast<float*>(cp + L.par), reinterpret_cast<float*>(cp + L.part)};
   A.tile_px = t.tile_px; A.tiles_per_sample = t.tps; A.nwg = t.nwg;
-  A.gx_tile_px = t.gx_tile_px; A.gx_tiles_per_sample = t.gx_tps;
-  A.t2x = t.t2x; A.t2y = t.t2y; A.nwg1 = t.nwg1; A.ncb = t.ncb;
+  A.gx_tile_px = t.gx_tile_px; A.gx_tiles_per_sample = t.gx_tps; A.fw_kw = t.fw_kw; A.gx_kw = t.gx_kw;
+  A.nwg_out = t.nwg_out; A.nwg1 = t.nwg1; A.act_ppt = t.act_ppt; A.act_hl_max = t.act_hl; A.ncb = t.ncb; A.nshare = t.nshare;
   sig = Sig{dtype, t.vec, 0, 0, 0, 0};
   return 0;
 }
@@ -1113,13 +1129,16 @@ static int head_forward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t s
     if (int e = launch_status("k_head_gemm<fwd>")) return e;
   }
   {
-    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return (a.g.hid + 7) / 8; });
+    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.g.hid; });
     LAUNCH(k_head_stats, grid, 0, st, G);
     if (int e = launch_status("k_head_stats")) return e;
   }
   {
-    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.nwg1; });
-    const size_t smem = (static_cast<size_t>(kHeadJC) * (kHeadT2 + 2) * (kHeadT2 + 2) + kHeadJC * 11) * sizeof(float);
+    int ohl = 0;
+    for (int l = 0; l < n; ++l) ohl = std::max(ohl, kHeadOutPx + 2 * (lv[l].g.W + 1));
+    for (int l = 0; l < n; ++l) { lv[l].out_hl_max = ohl; G.lv[l].out_hl_max = ohl; }
+    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.nwg_out; });
+    const size_t smem = std::max(static_cast<size_t>(4) * kHeadJO * ohl, static_cast<size_t>(16) * kWave) * sizeof(float);
     switch (sig.dtype) {
       case MGACBAM_F32: LAUNCH(k_head_out<float>, grid, smem, st, G); break;
       case MGACBAM_F16: LAUNCH(k_head_out<__half>, grid, smem, st, G); break;
@@ -1152,8 +1171,11 @@ static int head_backward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t 
   G.n = n;
   for (int l = 0; l < n; ++l) G.lv[l] = lv[l];
   {
-    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.nwg1; });
-    const size_t smem = (static_cast<size_t>(kHeadT2 + 2) * (kHeadT2 + 2) + 4 * kHeadJC * kHeadNStat) * sizeof(float);
+    int hl = 0;
+    for (int l = 0; l < n; ++l) hl = std::max(hl, lv[l].act_hl_max);
+    for (int l = 0; l < n; ++l) { lv[l].act_hl_max = hl; G.lv[l].act_hl_max = hl; }      // the reduction scratch sits behind the launch's longest run
+    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.nwg1 * ((a.g.hid + kHeadJC - 1) / kHeadJC); });
+    const size_t smem = (static_cast<size_t>(hl) + 4 * 4 * kHeadNStat) * sizeof(float);
     switch (sig.dtype) {
       case MGACBAM_F32: LAUNCH(k_head_bwd_act<float>, grid, smem, st, G); break;
       case MGACBAM_F16: LAUNCH(k_head_bwd_act<__half>, grid, smem, st, G); break;
@@ -1177,7 +1199,7 @@ static int head_backward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t 
     if (int e = launch_status("k_head_gemm<gx>")) return e;
   }
   {
-    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.ncb * kHeadGwWG; });
+    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.ncb * a.nshare; });
     size_t smem = 0;
     for (int l = 0; l < n; ++l) smem = std::max(smem, (5 * static_cast<size_t>(lv[l].g.hidp) + 1024) * sizeof(float));
 #define CALL_HW(Tt, Vv) LAUNCH((k_head_bwd_gw<Tt, Vv>), grid, smem, st, G)
@@ -1188,7 +1210,7 @@ static int head_backward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t 
     if (int e = launch_status("k_head_bwd_gw")) return e;
   }
   {
-    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return (a.g.hid * a.g.C + kBlock - 1) / kBlock; });
+    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return (a.g.hid * a.g.C + 63) / 64; });
     LAUNCH(k_head_bwd_gwf, grid, 0, st, G);
     if (int e = launch_status("k_head_bwd_gwf")) return e;
   }
@@ -1210,6 +1232,8 @@ extern "C" int mgahead_backward(const mgahead_bwd_level_t* levels, int n_levels,
     HeadArgs& A = args[l];
     A.x = L.x; A.gl = L.g_logits; A.gx = L.gx;
     A.gw1 = L.gw1; A.ggamma = L.gbn_weight; A.gbeta = L.gbn_bias; A.gwh = L.gwh; A.gbh = L.gbh;
+    A.accum_gx = (L.flags & MGAHEAD_BWD_ACCUM_GX) ? 1 : 0;
+    A.gl2 = L.g_logits2;
     const HeadScratchLayout SL = head_scratch_layout(L.B, L.C, L.H, L.W, L.p.hidden);
     char* sp = static_cast<char*>(L.scratch);
     A.s = HeadScratch{reinterpret_cast<float*>(sp + SL.ga), reinterpret_cast<float*>(sp + SL.part1), reinterpret_cast<float*>(sp + SL.kst),

@@ -31,6 +31,33 @@ class BlockConfig:
 
 
 _DTYPES = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+
+
+def _raw_stream(dev: torch.device) -> int:
+    """hipStream_t of torch's current stream on `dev` (the private accessor is ~10x cheaper than building a Stream object: this
+    sits on the eager path's per-call critical path)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+    except AttributeError:
+        return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` only when dev is not already current (the common case costs one integer compare)."""
+    __slots__ = ("dev", "guard")
+
+    def __init__(self, dev):
+        self.dev, self.guard = dev, None
+
+    def __enter__(self):
+        idx = self.dev.index
+        if idx is not None and idx != torch.cuda.current_device():
+            self.guard = torch.cuda.device(self.dev)
+            self.guard.__enter__()
+
+    def __exit__(self, *a):
+        if self.guard is not None:
+            self.guard.__exit__(*a)
 _USE_PROJ = bool(int(os.environ.get("MGACBAM_PROJ", "0")))
 # k_chan + k_apply as ONE x-resident launch (k_gate, MGACBAM_FWD_FUSE); MGACBAM_FUSE_FWD=0 restores the three-launch forward
 _FUSE_FWD = bool(int(os.environ.get("MGACBAM_FUSE_FWD", "1")))
@@ -40,6 +67,8 @@ _FOLD_BWD = _FUSE_FWD and bool(int(os.environ.get("MGACBAM_FOLD_BWD", "1")))
 # without it a time-out is still loud -- the tile is poisoned with NaN -- and handoff_report() reads every status word at once)
 _CHECK_HANDOFF = bool(int(os.environ.get("MGACBAM_CHECK_HANDOFF", "0")))
 SLOTS = 8  # tensors per level in the flat argument list: x, mask, w1, b1, w2, b2, wsa, beta
+_FWD_STAGES = _lib.FWD_ALL | (_lib.FWD_FUSE if _FUSE_FWD else 0)
+_BWD_STAGES = _lib.BWD_ALL | (_lib.BWD_FOLD if _FOLD_BWD else 0)
 
 
 class HandoffTimeout(RuntimeError):
@@ -184,7 +213,7 @@ class _PyramidFn(torch.autograd.Function):
         dev = flat[0].device
         if not flat[0].is_cuda:
             raise RuntimeError("mask_cbam: device tensors only (host tensors take the module's host path)")
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _raw_stream(dev)
         for l in range(n):
             x, mask, *params = flat[l * SLOTS:(l + 1) * SLOTS]
             cfg = cfgs[l]
@@ -213,9 +242,10 @@ class _PyramidFn(torch.autograd.Function):
             keep += [xc, m32, *pc]
             outs.append(y)
             meta.append(((None if mask is None else (mask.dtype, tuple(mask.shape))), proj))
-        with torch.cuda.device(dev):
-            stages = _lib.FWD_ALL | (_lib.FWD_FUSE if _FUSE_FWD else 0)
-            _lib.check(lib.mgacbam_forward_stages(levels, n, stages, stream), "mgacbam_forward_stages")
+        with _on_device(dev):
+            rc = lib.mgacbam_forward_stages(levels, n, _FWD_STAGES, stream)
+        if rc:
+            _lib.check(rc, "mgacbam_forward_stages")
         if _CHECK_HANDOFF:
             _check_status([(ls.buf, ls.key[2:7]) for ls in leases], "mask_cbam forward")
         ctx.save_for_backward(*keep)
@@ -257,9 +287,10 @@ class _PyramidFn(torch.autograd.Function):
                 mdtype, mshape = ctx.meta[l][0]
                 gmask = gmask.reshape(mshape).to(mdtype)
             grads += [gx, gmask, *pg]
-        with torch.cuda.device(dev):
-            stages = _lib.BWD_ALL | (_lib.BWD_FOLD if _FOLD_BWD else 0)
-            _lib.check(lib.mgacbam_backward_stages(levels, n, stages, torch.cuda.current_stream(dev).cuda_stream), "mgacbam_backward_stages")
+        with _on_device(dev):
+            rc = lib.mgacbam_backward_stages(levels, n, _BWD_STAGES, _raw_stream(dev))
+        if rc:
+            _lib.check(rc, "mgacbam_backward_stages")
         del hold
         if _CHECK_HANDOFF:
             _check_status([(ls.buf, ls.key[2:7]) for ls in ctx.leases], "mask_cbam backward")
@@ -557,10 +588,10 @@ class _HeadFn(torch.autograd.Function):
             pg = [torch.empty_like(t) for t in (w1, gamma, beta, wh, bh)]
             scratch = torch.empty(lib.mgahead_bwd_scratch_bytes(B, Cc, H, W, hid), dtype=torch.uint8, device=dev)
             L = levels[l]
-            L.x, L.g_logits, L.ctx, L.scratch, L.gx = xc.data_ptr(), gl.data_ptr(), cbuf.data_ptr(), scratch.data_ptr(), gx.data_ptr()
+            L.x, L.g_logits, L.g_logits2, L.ctx, L.scratch, L.gx = xc.data_ptr(), gl.data_ptr(), None, cbuf.data_ptr(), scratch.data_ptr(), gx.data_ptr()
             L.gw1, L.gbn_weight, L.gbn_bias, L.gwh, L.gbh = (t.data_ptr() for t in pg)
             L.p = _head_params(w1, gamma, beta, rmean, rvar, None, wh, bh, hid, eps, momentum, training)
-            L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[xc.dtype]
+            L.B, L.C, L.H, L.W, L.dtype, L.flags = B, Cc, H, W, _DTYPES[xc.dtype], 0
             hold += [gl, scratch]
             pg[0] = pg[0].view(w1_shape)
             grads += [gx, *pg]

@@ -26,7 +26,7 @@ class PyramidPlan:
     def __init__(self, shapes: Sequence[Tuple[int, int, int, int]], params: Sequence[Sequence[torch.Tensor]],
                  cfgs: Sequence[BlockConfig], dtype: torch.dtype = torch.float32, device="cuda",
                  with_mask: bool = True, want_gmask: bool = True, use_proj: bool = False,
-                 fuse_forward: Optional[bool] = None):
+                 fuse_forward: Optional[bool] = None, grad_bucket: Optional[torch.Tensor] = None):
         # fuse_forward: k_chan + k_apply as ONE x-resident launch, k_gate (MGACBAM_FWD_FUSE); None = env MGACBAM_FUSE_FWD (on)
         self.fuse_forward = bool(int(os.environ.get("MGACBAM_FUSE_FWD", "1"))) if fuse_forward is None else bool(fuse_forward)
         # transposed conv folded into the k_bwd_reduce1 launch (MGACBAM_BWD_FOLD) whenever the whole backward is one call
@@ -40,7 +40,11 @@ class PyramidPlan:
         dev = self.device
         self.x, self.mask, self.y, self.gy, self.gx, self.gmask, self.ctx, self.scratch = ([] for _ in range(8))
         n_grad = sum(p.numel() for ps in self.params for p in ps)
-        self.grad_bucket = torch.zeros(n_grad, dtype=torch.float32, device=dev)
+        if grad_bucket is not None:                              # a slice of a larger bucket owned by the caller (slice.SlicePlan)
+            assert grad_bucket.numel() == n_grad and grad_bucket.dtype == torch.float32 and grad_bucket.is_contiguous()
+            self.grad_bucket = grad_bucket
+        else:
+            self.grad_bucket = torch.zeros(n_grad, dtype=torch.float32, device=dev)
         self.param_grads: List[List[torch.Tensor]] = []
         self._fwd = (_lib.FwdLevel * self.n)()
         self._bwd = (_lib.BwdLevel * self.n)()
