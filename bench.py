@@ -427,7 +427,8 @@ def main():
         try:
             tj = json.load(open(tpath))
             traffic = tj.get(args.workload if args.dtype == "f32" else f"{args.workload}_{args.dtype}", {}).get(symbols[dom])
-            traffic_source = tj.get("_source")
+            src = tj.get("_source")
+            traffic_source = src.get(args.workload) if isinstance(src, dict) else src
         except Exception:
             traffic = None
     roofline = dict(bound="hbm", kernel=symbols[dom], stage=dom, achieved=kernels[dom]["GBps"], peak=HBM_PEAK_GBPS, unit="GB/s",

@@ -28,6 +28,12 @@ def test_reference_factory_built_our_blocks(report, scale):
         assert L["cls"] == "mga_yolo_amd.module.MaskCBAM" and L["i"] == i and L["f"] == [feat, head]      # U/nn/tasks.py:1763-1766
         assert L["type"].endswith("MaskCBAM") and L["np"] == L["ref_np"]
     assert R["detect_from"] == [23, 25, 27]
+    # the mask heads (layers 22/24/26, U/nn/tasks.py:1724-1731) are this package's MGAMaskHead too, and MGAModel._index_mask_heads
+    # (isinstance against the patched name, model/model.py:208-214) still finds them: the `seg` outputs were compared above
+    assert R["mask_heads"] == ["mga_yolo_amd.module.MGAMaskHead"] * 3
+    for i, feat in ((22, 15), (24, 18), (26, 21)):
+        L = R["layers"][str(i)]
+        assert L["cls"] == "mga_yolo_amd.module.MGAMaskHead" and L["f"] == feat and L["np"] == L["ref_np"]
     assert R["state_keys_equal"] and R["state_values_equal_same_seed"] and R["cross_load_strict"]
     assert R["eval_forward_rel_diff"] <= 1e-6 and R["train_forward_rel_diff"] <= 1e-6
     assert R["seg_criterion"]["ref"].startswith("mga_yolo.nn.losses") and R["seg_criterion"]["new"] == "mga_yolo_amd.segloss.SegmentationLoss"

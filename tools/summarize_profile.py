@@ -13,6 +13,7 @@ import json
 import os
 import re
 import shutil
+import subprocess
 import sys
 
 
@@ -61,7 +62,19 @@ def main(src, dst):
         print(wl)
         for k, v in sorted(out.items()):
             print(f"  {k:16s} avg {v.get('avg_us', 0):7.2f} us   HBM read {v['hbm_read_bytes'] / 1e6:8.1f} MB  write {v['hbm_write_bytes'] / 1e6:8.1f} MB")
-    json.dump(latest, open(os.path.join(os.path.dirname(os.path.abspath(dst)), "traffic_latest.json"), "w"), indent=1, sort_keys=True)
+    # traffic_latest.json keeps the newest figures per workload and says where each came from (bench.py quotes it as `traffic_source`)
+    lp = os.path.join(os.path.dirname(os.path.abspath(dst)), "traffic_latest.json")
+    merged = json.load(open(lp)) if os.path.exists(lp) else {}
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+    except Exception:
+        commit = "unknown"
+    src_tag = dict(merged.get("_source", {})) if isinstance(merged.get("_source"), dict) else {}
+    for wl, v in latest.items():
+        merged[wl] = v
+        src_tag[wl] = f"{os.path.basename(os.path.normpath(dst))} @ {commit}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (separate runs), FETCH_SIZE x2 (gfx950)"
+    merged["_source"] = src_tag
+    json.dump(merged, open(lp, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
