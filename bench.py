@@ -157,7 +157,7 @@ def time_kernels(plan, reps):
     return out
 
 
-def eager_module_step(workload, device, dtype_name, steps=60, warmup=10):
+def eager_module_step(workload, device, dtype_name, steps=60, warmup=10, engine_inline=False):
     """The path the reference's UNCHANGED layer loop takes (mga_yolo/model/model.py:57-64): three `MaskCBAM` modules called one
     after the other through autograd (one library call forward and one backward PER LEVEL, every launch issued from Python),
     no PyramidPlan, no hipGraph.  Returns ms per forward+backward step over the three levels."""
@@ -182,14 +182,22 @@ def eager_module_step(workload, device, dtype_name, steps=60, warmup=10):
             t.grad = None                                        # step (otherwise autograd adds into the old gradients: 24 extra kernels)
         ys = [mod([x, m]) for mod, (x, m, _) in zip(mods, data)]
         torch.autograd.backward(ys, [gy for _, _, gy in data])
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) * 1e3 / steps
+    # engine_inline: autograd's engine kept on the calling thread.  By default backward() hands the graph to a device worker thread and
+    # waits; that wake-up (~0.2 ms here) is paid once per backward() call -- for the WHOLE model in a real training step -- so the
+    # inline figure is the blocks' marginal cost inside a trainer, the default figure what a stand-alone three-node graph costs
+    prev = torch.autograd.is_multithreading_enabled()
+    torch.autograd.set_multithreading_enabled(not engine_inline)
+    try:
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / steps
+    finally:
+        torch.autograd.set_multithreading_enabled(prev)
 
 
 def slice_step(workload, device, steps=100, warmup=10):
@@ -440,9 +448,10 @@ def main():
                      frac=round(step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                      sum_kernel_us=round(sum(kt.values()), 1), event_pad_us=round(event_pad, 2))
 
-    eager_ms = None
+    eager_ms = eager_inline_ms = None
     if rank == 0 and world == 1 and not args.no_eager:
         eager_ms = round(eager_module_step(args.workload, device, args.dtype), 4)
+        eager_inline_ms = round(eager_module_step(args.workload, device, args.dtype, engine_inline=True), 4)
         from mga_yolo_amd import handoff_report
         handoff_report()
     slice_res = None
@@ -462,8 +471,8 @@ def main():
                                 grad_exchange=None if world == 1 else f"{'RCCL' if args.backend == 'nccl' else args.backend} all-reduce of one {plan.grad_bucket.numel() * 4} B bucket per step, overlapped with the next step's parameter-free k_pool",
                                 handoff_kernels=bool(plan.fuse_forward)),
                     roofline=roofline, step_roofline=step_roof, kernels=kernels, cpu_baseline=cpu,
-                    eager_module_ms_per_step=eager_ms, layer_loop_slice=slice_res,
-                    eager_module_note="the unchanged reference layer loop's path: three MaskCBAM modules through autograd, one library call per level each way, launches issued from Python (no PyramidPlan / hipGraph)",
+                    eager_module_ms_per_step=eager_ms, eager_module_ms_per_step_engine_inline=eager_inline_ms, layer_loop_slice=slice_res,
+                    eager_module_note="the unchanged reference layer loop's path: three MaskCBAM modules through autograd, one library call per level each way, launches issued from Python (no PyramidPlan / hipGraph), gradients reset to None every step as the trainer does; engine_inline = autograd engine on the calling thread (the blocks' marginal cost inside a whole-model backward, which pays the engine's worker-thread wake-up once for all layers)",
                     lib=_lib.load().mgacbam_build_info().decode())
         print(json.dumps(line))
     if world > 1:

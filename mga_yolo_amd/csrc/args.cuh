@@ -13,7 +13,10 @@ struct Geo {
   int proj_h;      // > 0: W1-projection planes of x are saved (forward) / available (backward); = hidden (<= kProjMax)
 };
 constexpr int kProjMax = 4;   // MGACBAM_PROJ_MAX_HIDDEN
-constexpr int kGateR = 16;    // channels a thread of the x-resident kernels keeps in registers (x VEC pixels each)
+#ifndef MGACBAM_GATE_R
+#define MGACBAM_GATE_R 16
+#endif
+constexpr int kGateR = MGACBAM_GATE_R;   // channels a thread of the x-resident kernels keeps in registers (x VEC pixels each)
 constexpr int kSyncPx = 16;   // a hand-off tile is at least this many pixels: ctx.sync holds ceil(HW/kSyncPx)+1 flags per sample
 
 // saved statistics (device pointers into the caller's ctx buffer) -- see mgacbam_ctx_layout_t

@@ -119,7 +119,7 @@ static int env_int(const char* name, int dflt) {
 // Tuning / test knobs come from the environment ONCE (first call) -- not per call: the eager path makes ~50 look-ups per step
 // otherwise.  mgacbam_reload_env() re-reads them (tests and tuning sweeps that change the environment in-process).
 struct Knobs {
-  int gate, chan_mintx, pool_tx, pool_cpt, chan_tx, chanf_tx, split_mlp, nt, half_vec, gate_h8, level_order, bwd_fold;
+  int gate, chan_mintx, pool_tx, pool_cpt, r2_cpt, chan_tx, chanf_tx, split_mlp, nt, half_vec, gate_h8, level_order, bwd_fold;
   int resident_wgs;        // MGACBAM_RESIDENT_WGS: override of the co-resident workgroup budget the hand-off eligibility is sized from
   int fault;               // MGACBAM_FAULT: fault injection for tests (args.cuh)
   unsigned spin_limit;     // MGACBAM_SPIN_LIMIT
@@ -131,7 +131,7 @@ static Knobs read_knobs() {
   k.pool_tx = env_int("MGACBAM_POOL_TX", 0); k.pool_cpt = env_int("MGACBAM_POOL_CPT", 0); k.chan_tx = env_int("MGACBAM_CHAN_TX", 0);
   k.nt = env_int("MGACBAM_NT", 1); k.half_vec = env_int("MGACBAM_HALF_VEC", 4); k.gate_h8 = env_int("MGACBAM_GATE_H8", 1);
   k.level_order = env_int("MGACBAM_LEVEL_ORDER", 1); k.bwd_fold = env_int("MGACBAM_BWD_FOLD", 1);
-  k.chanf_tx = env_int("MGACBAM_CHANF_TX", 0); k.split_mlp = env_int("MGACBAM_SPLIT_MLP", -1);
+  k.r2_cpt = env_int("MGACBAM_R2_CPT", 0); k.chanf_tx = env_int("MGACBAM_CHANF_TX", 0); k.split_mlp = env_int("MGACBAM_SPLIT_MLP", -1);
   k.resident_wgs = env_int("MGACBAM_RESIDENT_WGS", 0); k.fault = env_int("MGACBAM_FAULT", 0);
   const int sl = env_int("MGACBAM_SPIN_LIMIT", 0);
   k.spin_limit = sl > 0 ? static_cast<unsigned>(sl) : (1u << 20);
@@ -370,10 +370,10 @@ struct Sig {
 // per CU, else 1 (4 is instantiated and reachable through MGACBAM_POOL_CPT, but measured slower at every benchmark shape:
 // k_pool 80 us vs 91 us at config 4, 22 vs 26 us at config 2)
 template <typename Args>
-static int group_cpt(const Args* lv, int n) {
+static int group_cpt(const Args* lv, int n, int max_cpt = 2) {
   const int forced = knobs().pool_cpt;
   if (forced == 1 || forced == 2 || forced == 4) return forced;
-  for (int cpt = 2; cpt > 1; cpt /= 2) {
+  for (int cpt = max_cpt; cpt > 1; cpt /= 2) {
     long long blocks = 0;
     for (int l = 0; l < n; ++l) {
       const int tx = lv[l].t.pool_tx;
@@ -633,7 +633,10 @@ static int backward_args(const mgacbam_bwd_level_t& L, BwdArgs& A, Sig& sig) {
 static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStream_t st) {
   Group<BwdArgs> G;
   G.n = n;
-  const int cpt = group_cpt(lv, n);
+  // k_bwd_reduce2 re-reads three planes (g_planes x 2, cidx) per channel group: 4 channels per row halve that share of its loads
+  // (config 4: 88 -> 80 us) whenever the grid still fills the chip; k_pool (one mask plane per group) measured slower with 4
+  const int r2max = knobs().r2_cpt == 1 || knobs().r2_cpt == 2 || knobs().r2_cpt == 4 ? knobs().r2_cpt : 4;
+  const int cpt = group_cpt(lv, n, r2max);
   for (int l = 0; l < n; ++l) {
     lv[l].t.pool_cpt = cpt;
     const int cpb = (kBlock / lv[l].t.pool_tx) * cpt;

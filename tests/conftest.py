@@ -89,6 +89,16 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def elem_err(a, b, floor=1e-3):
+    """ELEMENT-wise relative error with an absolute floor: max_i |a_i - b_i| / max(|b_i|, floor * max|b|).  rel_err above is relative
+    to the tensor's scale, which leaves small-magnitude elements (e.g. dL/dmask of nearly saturated pixels) unconstrained in relative
+    terms; this bounds every element whose magnitude is at least `floor` of the scale."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    den = b.abs().clamp_min(floor * float(b.abs().max().clamp_min(1e-30)))
+    return float(((a - b).abs() / den).max())
+
+
 @pytest.fixture(scope="session")
 def checksums():
     return load_checksums()

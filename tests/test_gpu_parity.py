@@ -6,7 +6,7 @@ import os
 import pytest
 import torch
 
-from conftest import checksum, golden_case_names, load_golden, rel_err, synth
+from conftest import checksum, elem_err, golden_case_names, load_golden, rel_err, synth
 from oracle import maskcbam_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -102,6 +102,13 @@ def test_fwd_bwd_vs_reference_golden(F, name):
         e = rel_err(g[k], d["out"][k])
         if not e < TOL:
             report.append(f"{k} {e:.3e}")
+        # element-wise as well: every element of at least 1e-3 of the tensor's scale within 1e-3 of ITS OWN value (smaller ones
+        # within 1e-6 of the scale) -- the tensor-scale bound above says nothing about small elements
+        ee = elem_err(g[k], d["out"][k])
+        if not ee < 1e-3:
+            report.append(f"{k} element-wise {ee:.3e}")
+    if not elem_err(y, d["out"]["y"]) < 1e-3:
+        report.append(f"y element-wise {elem_err(y, d['out']['y']):.3e}")
     assert not report, f"{name}: " + "; ".join(report)
 
 

@@ -1,27 +1,16 @@
 """The layer-loop slice around the hot path, as MGAModel runs it (mga_yolo/model/model.py:57-74, 196-214): per level a mask head
-(1x1 conv -> BN -> SiLU -> 3x3 conv, mga_yolo/nn/modules/segmentation.py:81-110; plain torch here, it is not part of the built
-rows) produces mask logits, `[feat, mask]` goes into MaskCBAM, the logits also go into the multi-scale segmentation loss.  On the
-device MaskCBAM and the loss are the HIP paths; the same slice on the host (module host path + loss oracle) is the reference.
+(1x1 conv -> BN -> SiLU -> 3x3 conv, mga_yolo/nn/modules/segmentation.py:81-110) produces mask logits, `[feat, mask]` goes into
+MaskCBAM, the logits also go into the multi-scale segmentation loss.  On the device ALL THREE are the HIP paths (this package's
+MGAMaskHead, MaskCBAM, SegmentationLoss); the same slice on the host (the modules' host paths + the loss oracle) is the reference.
 Checks the seams: dL/dmask from the block flows into the head together with the loss gradient, one backward over all of it."""
 import copy
 
 import pytest
 import torch
-import torch.nn as nn
 
 from oracle import segloss_oracle as SO
 
 pytestmark = pytest.mark.gpu
-
-
-class _Head(nn.Module):
-    def __init__(self, c_in, hidden):
-        super().__init__()
-        self.proj = nn.Sequential(nn.Conv2d(c_in, hidden, 1, bias=False), nn.BatchNorm2d(hidden), nn.SiLU())
-        self.head = nn.Conv2d(hidden, 1, 3, padding=1, bias=True)
-
-    def forward(self, x):
-        return self.head(self.proj(x))
 
 
 def _slice(feats, heads, blocks, criterion, targets):
@@ -36,7 +25,7 @@ def _slice(feats, heads, blocks, criterion, targets):
 
 
 def test_head_block_loss_slice_matches_the_host_statement(built_lib):
-    from mga_yolo_amd import MaskCBAM, SegLossConfig, SegmentationLoss
+    from mga_yolo_amd import MGAMaskHead as _Head, MaskCBAM, SegLossConfig, SegmentationLoss
     torch.manual_seed(0)
     B, lv = 4, [(64, 16, 24, 24), (128, 32, 12, 12), (256, 64, 6, 6)]
     heads = [_Head(c, h) for c, h, _, _ in lv]
@@ -56,10 +45,11 @@ def test_head_block_loss_slice_matches_the_host_statement(built_lib):
     loss_h, logs_h, ys_h = _slice(h_feats, h_heads, h_blocks, crit_h, targets)
     loss_h.backward()
 
-    # device: torch head, HIP block, HIP loss
+    # device: HIP mask head, HIP block, HIP loss
     d_heads = [copy.deepcopy(h).cuda() for h in heads]
     d_blocks = [copy.deepcopy(b).cuda() for b in blocks]
     d_feats = [f.cuda().requires_grad_(True) for f in feats]
+    assert all(h.hip_path() and h.training for h in d_heads)
     loss_d, logs_d, ys_d = _slice(d_feats, d_heads, d_blocks, SegmentationLoss(SegLossConfig(**cfg)), [t.cuda() for t in targets])
     loss_d.backward()
 
