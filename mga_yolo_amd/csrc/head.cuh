@@ -58,14 +58,16 @@ struct HeadArgs {
   int tile_px, tiles_per_sample, nwg;          // 1-D pixel tiling of k_head_gemm<FWD> (nwg = rows of the partial sums)
   int gx_tile_px, gx_tiles_per_sample;         // ... of k_head_gemm<GX>
   int fw_kw, gx_kw;                            // waves of a workgroup that split the K steps (1, 2, 4)
+  int fw_mtw, gx_mtw;                          // M tiles per wave (template parameter of the launch the level rides in)
   int nwg_out, out_hl_max;                     // k_head_out: workgroups (runs of kHeadOutPx pixels), LDS floats per staged channel (launch maximum)
   int nwg1, act_ppt, act_hl_max;               // k_head_bwd_act: pixel runs of the level, pixels per thread, LDS floats of the launch's longest run
   int ncb, nshare;                             // k_head_bwd_gw: channel blocks, pixel shares per block (= partial sets of dW1)
   int accum_gx;                                // MGAHEAD_BWD_ACCUM_GX: gx += W1^T g_z
 };
 
-constexpr int kHeadMTW = 4;      // 16-output tiles a wave accumulates at once (x VEC sub-tiles x 4 registers)
-constexpr int kHeadLdsA = 4096;  // floats of LDS for the staged A operand (16 KB: one launch covers all levels, so the largest level's block sets every level's occupancy)
+constexpr int kHeadMTW = 4;      // upper bound of the 16-output tiles a wave accumulates at once (template MTW = 1, 2, 4: 16 registers x VEC/4... each;
+                                 // the forward takes min(4, tiles of the level) so that x is read once, gx takes 2: its B operand is small and cheap to re-read)
+constexpr int kHeadLdsX = 4096;  // floats of LDS for the K-split reduction of k_head_gemm (4 waves x VEC x 4 registers x 64 lanes)
 constexpr int kHeadJC = 4;       // k_head_bwd_act: hidden channels per workgroup (= one batch of z loads: every workgroup is one memory round trip deep)
 constexpr int kHeadCB = 64;      // k_head_bwd_gw: channels of x per workgroup (4 N tiles)
 constexpr int kHeadNStat = 12;   // per-channel partial sums of k_head_bwd_act: g_a, g_a*zhat, 9 taps of dW_h, db_h
@@ -78,20 +80,20 @@ __device__ __forceinline__ float siluf(float a) { return a / (1.f + expf(-a)); }
 //   lane l: k l/16, group l%16), D 16 x 16 in 4 registers (lane l, register v: output 4*(l/16)+v, group l%16).  With VEC = 4 a lane loads
 //   16 B = 4 consecutive pixels of its k-channel (a wave-load = 4 channels x 256 B contiguous) and register r of that vector is the B
 //   operand of sub-tile r: 64 pixels per wave and K step; VEC = 1 (H*W % 4 != 0): one dword per lane, 16 pixels per wave.
-//   Workgroup = 4 waves = MW (along M) x PW (along pixels); the weight block [M block][K block] is staged in LDS in the A layout
-//   ([kstep][mtile][lane]: conflict-free ds_read_b32).  Blocks: M in blocks of 16*kHeadMTW*MW outputs, K in blocks that fit kHeadLdsA.
+//   Workgroup = 4 waves = MW (along M) x KW (along K) x PW (along pixels); M in blocks of 16*kHeadMTW*MW outputs.  The weights are
+//   read from global memory directly in the A layout, batch by batch together with the activations (no LDS staging, no barriers).
 // ---------------------------------------------------------------------------------------------------------------------------
-template <typename T, int VEC, bool GX>
+template <typename T, int VEC, bool GX, int MTW>
 __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, float* smem) {
   const HeadGeo& g = A.g;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lk = lane >> 4, ln = lane & 15;
   const int M = GX ? g.C : g.hid, K = GX ? g.hid : g.C;
   const int MT = ((GX ? g.cp : g.hidp)) >> 4;
-  const int MW = min(4, (MT + kHeadMTW - 1) / kHeadMTW);        // 1, 2 or 4 (MT = 3 tiles of waves -> 4)
+  const int MW = min(4, (MT + MTW - 1) / MTW);        // 1, 2 or 4 (3 -> 4)
   const int MWp = MW == 3 ? 4 : MW;
-  // KW waves split the K steps of every block (levels with few pixels and a long K: the workgroup's chain of dependent memory round
-  // trips shrinks KW-fold; their accumulators are summed through LDS, fixed order, before the epilogue)
+  // KW waves split the K steps (levels with few pixels and a long K: the workgroup's chain of dependent memory round trips shrinks
+  // KW-fold; their accumulators are summed through LDS, fixed order, before the epilogue)
   const int KW = GX ? A.gx_kw : A.fw_kw;
   const int PW = 4 / (MWp * KW);
   const int mw = wave % MWp, kwi = (wave / MWp) % KW, pw = wave / (MWp * KW);
@@ -101,104 +103,75 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
   const int px = tile * (GX ? A.gx_tile_px : A.tile_px) + pw * WPX + ln * VEC;   // first pixel of this lane
   const bool px_ok = px < g.HW;
   const size_t pxo = px_ok ? px : 0;
-  const int mblk = kHeadMTW * MWp;                              // M tiles per block
-  const int rows = min(MT, mblk) * 16;
-  const int KB = min((K + 3) & ~3, max(4, (kHeadLdsA / rows) & ~3));   // K per LDS block (multiple of 4)
-  float* s_kst = smem + kHeadLdsA;                              // GX: per-hidden-channel constants of g_z [5][hidp]
+  const int mblk = MTW * MWp;                              // M tiles per block
+  float* s_kst = smem;                                          // GX: per-hidden-channel constants of g_z [5][hidp]
+  float* s_sum = smem;                                          // FWD: [PW][2][hidp] tile sums
+  float* s_x = smem + 8 * g.hidp;                               // K-split reduction scratch [4 waves][VEC][4][64]
   if (GX) {
     for (int i = tid; i < 5 * g.hidp; i += kBlock) s_kst[i] = A.s.kst[i];
+    __syncthreads();
   }
-  float* s_sum = smem + kHeadLdsA;                              // FWD: [PW][2][hidp] tile sums
   const T* xb = GX ? nullptr : static_cast<const T*>(A.x) + static_cast<size_t>(b) * g.C * g.HW + pxo;
   const float* gab = GX ? A.s.ga + static_cast<size_t>(b) * g.hid * g.HW + pxo : nullptr;
   const float* zb = A.c.z + static_cast<size_t>(b) * g.hid * g.HW + pxo;
+  const int ksteps = (K + 3) >> 2;
+  const int kper = (ksteps + KW - 1) / KW;                      // this wave's share of the K steps: [kbeg, kend)
+  const int kbeg = kwi * kper, kend = min(ksteps, kbeg + kper);
 
   for (int mt0 = 0; mt0 < MT; mt0 += mblk) {
     const int mtn = min(mblk, MT - mt0);                        // tiles in this block
-    v4f32 acc[kHeadMTW][VEC];
+    v4f32 acc[MTW][VEC];
 #pragma unroll
-    for (int t = 0; t < kHeadMTW; ++t)
+    for (int t = 0; t < MTW; ++t)
 #pragma unroll
       for (int r = 0; r < VEC; ++r) acc[t][r] = v4f32{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += KB) {
-      const int kn = min(KB, K - k0);
-      const int ksteps = (kn + 3) >> 2;
-      __syncthreads();                                          // previous block consumed (and s_kst written)
-      {
-        // source-major walk (coalesced reads of W1, scattered LDS writes into the A layout), SU loads in flight per thread
-        const int rowsb = mtn * 16, knp = ksteps * 4;
-        const int total = rowsb * knp;
-        constexpr int SU = 8;
-        for (int e0 = tid; e0 < total; e0 += kBlock * SU) {
-          float w[SU];
+    // K steps in batches of KU.  BOTH operands of a batch are requested before its first MFMA: the activations (16-B loads, 4 channels x
+    // 256 B per wave-load) and the weights, read from global memory straight in the MFMA lane layout (W1 is <= 64 KB and shared by
+    // every workgroup: L1 / L2 hits) -- no LDS staging, no barrier in the loop; a workgroup is one or two memory round trips deep.
+    constexpr int KU = GX ? 4 : 8;
+    for (int ks0 = kbeg; ks0 < kend; ks0 += KU) {
+      float bv[KU][VEC], zq[GX ? KU : 1][VEC], aw[KU][MTW];
 #pragma unroll
-          for (int u = 0; u < SU; ++u) {
-            const int e = e0 + u * kBlock;
-            int ol, kq;
-            if (GX) { kq = e / rowsb; ol = e - kq * rowsb; }     // W1[kk][out]: contiguous in out
-            else { ol = e / knp; kq = e - ol * knp; }            // W1[out][kk]: contiguous in kk
-            const int out = mt0 * 16 + ol, kk = k0 + kq;
-            w[u] = 0.f;
-            if (e < total && out < M && kk < k0 + kn)
-              w[u] = GX ? A.p.w1[static_cast<size_t>(kk) * g.C + out] : A.p.w1[static_cast<size_t>(out) * g.C + kk];
-          }
+      for (int u = 0; u < KU; ++u) {
+        const int kk = (ks0 + u) * 4 + lk;                      // this lane's k channel
+        const bool kok = (ks0 + u) < kend && kk < K;
 #pragma unroll
-          for (int u = 0; u < SU; ++u) {
-            const int e = e0 + u * kBlock;
-            if (e < total) {
-              int ol, kq;
-              if (GX) { kq = e / rowsb; ol = e - kq * rowsb; } else { ol = e / knp; kq = e - ol * knp; }
-              smem[((kq >> 2) * mtn + (ol >> 4)) * 64 + (kq & 3) * 16 + (ol & 15)] = w[u];
-            }
+        for (int r = 0; r < VEC; ++r) bv[u][r] = 0.f;
+        if (GX) {
+#pragma unroll
+          for (int r = 0; r < VEC; ++r) zq[u][r] = 0.f;
+          if (kok && px_ok) {
+            load_vec<float, VEC>(gab + static_cast<size_t>(kk) * g.HW, bv[u]);
+            load_vec<float, VEC>(zb + static_cast<size_t>(kk) * g.HW, zq[u]);
           }
+        } else if (kok && px_ok) {
+          load_vec<T, VEC>(xb + static_cast<size_t>(kk) * g.HW, bv[u]);
+        }
+#pragma unroll
+        for (int t = 0; t < MTW; ++t) {
+          const int mt = mw * MTW + t;
+          const int out = (mt0 + mt) * 16 + ln;
+          aw[u][t] = 0.f;
+          if (kok && mt < mtn && out < M)
+            aw[u][t] = GX ? A.p.w1[static_cast<size_t>(kk) * g.C + out] : A.p.w1[static_cast<size_t>(out) * g.C + kk];
         }
       }
-      __syncthreads();
-      // K steps in batches of KU: all of a batch's loads are issued before the first MFMA (a K step per memory round trip would make
-      // the workgroup a chain of C/4 dependent latencies: 64 of them at C = 256)
-      constexpr int KU = GX ? 4 : 8;
-      const int kper = (ksteps + KW - 1) / KW;                  // this wave's share of the block's K steps: [kwi*kper, ...)
-      const int kend = min(ksteps, (kwi + 1) * kper);
-      for (int ks0 = kwi * kper; ks0 < kend; ks0 += KU) {
-        float bv[KU][VEC], zq[GX ? KU : 1][VEC];
 #pragma unroll
-        for (int u = 0; u < KU; ++u) {
-          const int kk = k0 + (ks0 + u) * 4 + lk;               // this lane's k channel
-          const bool ok = px_ok && (ks0 + u) < kend && kk < k0 + kn;
+      for (int u = 0; u < KU; ++u) {
+        if (ks0 + u < kend) {                                   // uniform per wave
+          if (GX) {                                             // g_z = k_j (g_a - gbeta_j/n - zhat gamma'_j/n), zhat = (z - mean) rstd
+            const int kk = min((ks0 + u) * 4 + lk, g.hidp - 1);
+            const float kj = s_kst[kk], mean = s_kst[g.hidp + kk], rstd = s_kst[2 * g.hidp + kk];
+            const float gbn = s_kst[3 * g.hidp + kk], ggn = s_kst[4 * g.hidp + kk];
 #pragma unroll
-          for (int r = 0; r < VEC; ++r) bv[u][r] = 0.f;
-          if (GX) {
-#pragma unroll
-            for (int r = 0; r < VEC; ++r) zq[u][r] = 0.f;
-            if (ok) {
-              load_vec<float, VEC>(gab + static_cast<size_t>(kk) * g.HW, bv[u]);
-              load_vec<float, VEC>(zb + static_cast<size_t>(kk) * g.HW, zq[u]);
-            }
-          } else if (ok) {
-            load_vec<T, VEC>(xb + static_cast<size_t>(kk) * g.HW, bv[u]);
+            for (int r = 0; r < VEC; ++r) bv[u][r] = kj * (bv[u][r] - gbn - (zq[u][r] - mean) * rstd * ggn);
+            // (lanes whose loads were skipped hold g_a = z = 0: their g_z meets a ZERO weight, or its result row is never stored)
           }
-        }
 #pragma unroll
-        for (int u = 0; u < KU; ++u) {
-          const int ks = ks0 + u;
-          if (ks < kend) {                                      // uniform per wave
-            if (GX) {                                           // g_z = k_j (g_a - gbeta_j/n - zhat gamma'_j/n), zhat = (z - mean) rstd
-              const int kk = min(k0 + ks * 4 + lk, g.hidp - 1);
-              const float kj = s_kst[kk], mean = s_kst[g.hidp + kk], rstd = s_kst[2 * g.hidp + kk];
-              const float gbn = s_kst[3 * g.hidp + kk], ggn = s_kst[4 * g.hidp + kk];
+          for (int t = 0; t < MTW; ++t) {
+            if (mw * MTW + t < mtn) {                       // uniform per wave
 #pragma unroll
-              for (int r = 0; r < VEC; ++r) bv[u][r] = kj * (bv[u][r] - gbn - (zq[u][r] - mean) * rstd * ggn);
-              // (lanes whose load was skipped hold g_a = z = 0: their g_z is some finite number times a ZERO weight in A, or is
-              //  never stored -- except past H*W, where the result row is not stored either)
-            }
-#pragma unroll
-            for (int t = 0; t < kHeadMTW; ++t) {
-              const int mt = mw * kHeadMTW + t;
-              if (mt < mtn) {                                   // uniform per wave
-                const float a = smem[(ks * mtn + mt) * 64 + lane];
-#pragma unroll
-                for (int r = 0; r < VEC; ++r) acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[u][r], acc[t][r], 0, 0, 0);
-              }
+              for (int r = 0; r < VEC; ++r) acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[u][t], bv[u][r], acc[t][r], 0, 0, 0);
             }
           }
         }
@@ -207,13 +180,13 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
     // ---- K split: sum the KW waves' accumulators (wave kwi = 0 keeps the result) ------------------------------------------------------
     if (KW > 1) {
 #pragma unroll
-      for (int t = 0; t < kHeadMTW; ++t) {
-        __syncthreads();                                        // (first trip: the LDS block is consumed)
+      for (int t = 0; t < MTW; ++t) {
+        __syncthreads();
         if (kwi > 0) {
 #pragma unroll
           for (int r = 0; r < VEC; ++r)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) smem[((wave * VEC + r) * 4 + v) * 64 + lane] = acc[t][r][v];
+            for (int v = 0; v < 4; ++v) s_x[((wave * VEC + r) * 4 + v) * 64 + lane] = acc[t][r][v];
         }
         __syncthreads();
         if (kwi == 0) {
@@ -222,18 +195,17 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
 #pragma unroll
             for (int r = 0; r < VEC; ++r)
 #pragma unroll
-              for (int v = 0; v < 4; ++v) acc[t][r][v] += smem[((ow * VEC + r) * 4 + v) * 64 + lane];
+              for (int v = 0; v < 4; ++v) acc[t][r][v] += s_x[((ow * VEC + r) * 4 + v) * 64 + lane];
           }
         }
       }
     }
     // ---- epilogue of this M block -------------------------------------------------------------------------------------------
-    if (!GX && g.training) __syncthreads();                     // LDS block consumed before s_sum (separate region, but keep waves together)
-    float oldv[GX ? kHeadMTW : 1][GX ? 4 : 1][VEC];             // GX + accumulate: every old value is requested before the first store
+    float oldv[GX ? MTW : 1][GX ? 4 : 1][VEC];             // GX + accumulate: every old value is requested before the first store
     if (GX && A.accum_gx && kwi == 0) {
 #pragma unroll
-      for (int t = 0; t < kHeadMTW; ++t) {
-        const int mt = mw * kHeadMTW + t;
+      for (int t = 0; t < MTW; ++t) {
+        const int mt = mw * MTW + t;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int out = (mt0 + mt) * 16 + lk * 4 + v;
@@ -245,8 +217,8 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
       }
     }
 #pragma unroll
-    for (int t = 0; t < kHeadMTW; ++t) {
-      const int mt = mw * kHeadMTW + t;
+    for (int t = 0; t < MTW; ++t) {
+      const int mt = mw * MTW + t;
       if (mt < mtn && kwi == 0) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -278,7 +250,7 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
       }
     }
   }
-  if (!GX && g.training) {                                      // tile sums of z and z^2 per output channel (hid <= 16*kHeadMTW*4: one M block)
+  if (!GX && g.training) {                                      // tile sums of z and z^2 per output channel
     __syncthreads();
     float* part = A.c.part + static_cast<size_t>(wg) * 2 * g.hidp;
     for (int i = tid; i < 2 * g.hidp; i += kBlock) {
@@ -289,12 +261,12 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
   }
 }
 
-template <typename T, int VEC, bool GX>
+template <typename T, int VEC, bool GX, int MTW>
 __global__ __launch_bounds__(kBlock) void k_head_gemm(const Group<HeadArgs> G) {
   extern __shared__ __align__(16) float smem[];
   int local;
   const int l = find_level(G, blockIdx.x, local);
-  head_gemm_body<T, VEC, GX>(G.lv[l], local, smem);
+  head_gemm_body<T, VEC, GX, MTW>(G.lv[l], local, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -1014,11 +1014,11 @@ static int head_check_shape(int B, int C, int H, int W, int hidden) {
     return fail(MGACBAM_E_SHAPE, "mask head: tensor too large B=%d C=%d H=%d W=%d", B, C, H, W);
   return 0;
 }
-struct HeadTiling { int vec, hidp, cp, tile_px, tps, nwg, gx_tile_px, gx_tps, fw_kw, gx_kw, nwg_out, nwg1, act_ppt, act_hl, ncb, nshare; };
+struct HeadTiling { int vec, hidp, cp, tile_px, tps, nwg, gx_tile_px, gx_tps, fw_kw, gx_kw, fw_mtw, gx_mtw, nwg_out, nwg1, act_ppt, act_hl, ncb, nshare; };
 // wave arrangement of k_head_gemm (head.cuh): MW waves along M for `mtiles` 16-output tiles, KW waves along K when K is long (a chain of
 // K/4 dependent steps otherwise), the rest along pixels
-static void head_waves(int mtiles, int K, int& pw, int& kw) {
-  int mw = std::min(4, (mtiles + kHeadMTW - 1) / kHeadMTW);
+static void head_waves(int mtiles, int mtw, int K, int& pw, int& kw) {
+  int mw = std::min(4, (mtiles + mtw - 1) / mtw);
   if (mw == 3) mw = 4;
   const int rest = 4 / mw;
   kw = K >= 128 ? rest : 1;
@@ -1030,11 +1030,13 @@ static HeadTiling head_tiling(int B, int C, int H, int W, int hidden) {
   t.vec = (HW % 4 == 0) ? 4 : 1;
   t.hidp = (hidden + 15) & ~15; t.cp = (C + 15) & ~15;
   int pw;
-  head_waves(t.hidp / 16, C, pw, t.fw_kw);
+  t.fw_mtw = t.hidp / 16 >= 2 ? 4 : 1;                              // forward: hidden <= 16 runs under the one-tile template (light workgroups), the rest under the 4-tile one
+  t.gx_mtw = 2;                                                     // gx: its B operand (g_a, z: E/4 each) is cheap to re-read; light workgroups
+  head_waves(t.hidp / 16, t.fw_mtw, C, pw, t.fw_kw);
   t.tile_px = pw * 16 * t.vec;
   t.tps = (HW + t.tile_px - 1) / t.tile_px;
   t.nwg = B * t.tps;
-  head_waves(t.cp / 16, hidden, pw, t.gx_kw);
+  head_waves(t.cp / 16, t.gx_mtw, hidden, pw, t.gx_kw);
   t.gx_tile_px = pw * 16 * t.vec;
   t.gx_tps = (HW + t.gx_tile_px - 1) / t.gx_tile_px;
   t.nwg_out = B * ((HW + kHeadOutPx - 1) / kHeadOutPx);
@@ -1100,14 +1102,14 @@ static int head_common(const mgahead_params_t& P, int B, int C, int H, int W, in
   A.c = HeadCtx{reinterpret_cast<float*>(cp + L.z), reinterpret_cast<float*>(cp + L.mean), reinterpret_cast<float*>(cp + L.rstd),
                 reinterpret_cast<float*>(cp + L.par), reinterpret_cast<float*>(cp + L.part)};
   A.tile_px = t.tile_px; A.tiles_per_sample = t.tps; A.nwg = t.nwg;
-  A.gx_tile_px = t.gx_tile_px; A.gx_tiles_per_sample = t.gx_tps; A.fw_kw = t.fw_kw; A.gx_kw = t.gx_kw;
+  A.gx_tile_px = t.gx_tile_px; A.gx_tiles_per_sample = t.gx_tps; A.fw_kw = t.fw_kw; A.gx_kw = t.gx_kw; A.fw_mtw = t.fw_mtw; A.gx_mtw = t.gx_mtw;
   A.nwg_out = t.nwg_out; A.nwg1 = t.nwg1; A.act_ppt = t.act_ppt; A.act_hl_max = t.act_hl; A.ncb = t.ncb; A.nshare = t.nshare;
   sig = Sig{dtype, t.vec, 0, 0, 0, 0};
   return 0;
 }
 static size_t head_gemm_smem(const HeadArgs* lv, int n) {
   size_t m = 0;
-  for (int l = 0; l < n; ++l) m = std::max(m, (static_cast<size_t>(kHeadLdsA) + 8 * lv[l].g.hidp) * sizeof(float));
+  for (int l = 0; l < n; ++l) m = std::max(m, (static_cast<size_t>(kHeadLdsX) + 8 * lv[l].g.hidp) * sizeof(float));
   return m;
 }
 template <typename Fn>
@@ -1122,14 +1124,35 @@ static int head_forward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t s
   G.n = n;
   for (int l = 0; l < n; ++l) G.lv[l] = lv[l];
   {
-    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.nwg; });
+    // two launches at most: the levels that need ONE accumulator tile per wave (hidden <= 16: the largest feature map, whose workgroups
+    // should stay light) and the rest together (template = their largest need); each level alone is latency-bound, so levels that can
+    // share a launch overlap each other
     const size_t smem = head_gemm_smem(lv, n);
-#define CALL_HP(Tt, Vv) LAUNCH((k_head_gemm<Tt, Vv, false>), grid, smem, st, G)
-    if (sig.dtype == MGACBAM_F32) { if (sig.vec == 4) { CALL_HP(float, 4); } else { CALL_HP(float, 1); } }
-    else if (sig.dtype == MGACBAM_F16) { if (sig.vec == 4) { CALL_HP(__half, 4); } else { CALL_HP(__half, 1); } }
-    else { if (sig.vec == 4) { CALL_HP(bf16_t, 4); } else { CALL_HP(bf16_t, 1); } }
+    for (int pass = 0; pass < 2; ++pass) {
+      Group<HeadArgs> Gm;
+      Gm.n = 0;
+      int grid = 0, mtw = 1;
+      for (int l = 0; l < n; ++l)
+        if ((lv[l].fw_mtw == 1) == (pass == 0)) {
+          Gm.lv[Gm.n] = lv[l]; Gm.start[Gm.n] = grid; grid += lv[l].nwg; ++Gm.n;
+          mtw = std::max(mtw, lv[l].fw_mtw);
+        }
+      if (!Gm.n) continue;
+      Gm.start[Gm.n] = grid;
+      for (int l = 0; l < Gm.n; ++l) {                            // the wave arrangement follows the template the level runs under
+        int pw;
+        head_waves(Gm.lv[l].g.hidp / 16, mtw, Gm.lv[l].g.C, pw, Gm.lv[l].fw_kw);
+        if (pw * 16 * sig.vec != Gm.lv[l].tile_px) return fail(MGACBAM_E_SHAPE, "mask head: inconsistent tiling");   // (cannot happen: see head_tiling)
+      }
+#define CALL_HP3(Tt, Vv, Mm) LAUNCH((k_head_gemm<Tt, Vv, false, Mm>), grid, smem, st, Gm)
+#define CALL_HP(Tt, Vv) { if (mtw == 1) { CALL_HP3(Tt, Vv, 1); } else if (mtw == 2) { CALL_HP3(Tt, Vv, 2); } else { CALL_HP3(Tt, Vv, 4); } }
+      if (sig.dtype == MGACBAM_F32) { if (sig.vec == 4) { CALL_HP(float, 4); } else { CALL_HP(float, 1); } }
+      else if (sig.dtype == MGACBAM_F16) { if (sig.vec == 4) { CALL_HP(__half, 4); } else { CALL_HP(__half, 1); } }
+      else { if (sig.vec == 4) { CALL_HP(bf16_t, 4); } else { CALL_HP(bf16_t, 1); } }
 #undef CALL_HP
-    if (int e = launch_status("k_head_gemm<fwd>")) return e;
+#undef CALL_HP3
+      if (int e = launch_status("k_head_gemm<fwd>")) return e;
+    }
   }
   {
     const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.g.hid; });
@@ -1194,7 +1217,7 @@ static int head_backward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t 
   {
     const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.g.B * a.gx_tiles_per_sample; });
     const size_t smem = head_gemm_smem(lv, n);
-#define CALL_HX(Tt, Vv) LAUNCH((k_head_gemm<Tt, Vv, true>), grid, smem, st, G)
+#define CALL_HX(Tt, Vv) LAUNCH((k_head_gemm<Tt, Vv, true, 2>), grid, smem, st, G)
     if (sig.dtype == MGACBAM_F32) { if (sig.vec == 4) { CALL_HX(float, 4); } else { CALL_HX(float, 1); } }
     else if (sig.dtype == MGACBAM_F16) { if (sig.vec == 4) { CALL_HX(__half, 4); } else { CALL_HX(__half, 1); } }
     else { if (sig.vec == 4) { CALL_HX(bf16_t, 4); } else { CALL_HX(bf16_t, 1); } }
