@@ -79,6 +79,7 @@ struct BwdArgs {
   int nt;       // hw tiles of k_bwd_reduce1
   int nconv;    // k_bwd_convT tiles of this level (B * tiles_y * tiles_x)
   int nwsa;     // k_bwd_wsa tiles of this level: one dWsa partial each
+  int nrole;    // role workgroups of k_bwd_reduce2 that work through those tiles (<= nwsa)
   int npg;      // parameter-gradient workgroups of this level (k_bwd_params roles)
   int ncg;      // channel groups per sample of k_bwd_reduce2
   int nflag;    // flags per sample in c.sync

@@ -442,8 +442,14 @@ __global__ __launch_bounds__(kBlock) void k_bwd_reduce2(const Group<BwdArgs> G) 
   const int l = find_level(G, blockIdx.x, local);
   const BwdArgs& A = G.lv[l];
   if (ROLES) {
-    const int npad = (A.nwsa + 7) & ~7;                         // keeps the streaming ids' id % 8 <-> sample alignment
-    if (local < npad) { if (local < A.nwsa) bwd_wsa_body<7>(A, local, smem); return; }
+    // A.nrole role workgroups share the level's A.nwsa dWsa tiles (tile t -> role t % nrole, one after the other): the host sizes nrole to
+    // the slots the streaming workgroups leave idle, so that the roles displace nothing and finish inside the streaming time
+    const int npad = (A.nrole + 7) & ~7;                        // keeps the streaming ids' id % 8 <-> sample alignment
+    if (local < npad) {
+      if (local < A.nrole)
+        for (int t = local; t < A.nwsa; t += A.nrole) { bwd_wsa_body<7>(A, t, smem); __syncthreads(); }
+      return;
+    }
     local -= npad;
   }
   bwd_reduce2_body<T, VEC, CPT>(A, local, smem);

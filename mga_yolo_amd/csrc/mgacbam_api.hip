@@ -119,7 +119,7 @@ static int env_int(const char* name, int dflt) {
 // Tuning / test knobs come from the environment ONCE (first call) -- not per call: the eager path makes ~50 look-ups per step
 // otherwise.  mgacbam_reload_env() re-reads them (tests and tuning sweeps that change the environment in-process).
 struct Knobs {
-  int gate, chan_mintx, pool_tx, pool_cpt, r2_cpt, chan_tx, chanf_tx, split_mlp, nt, half_vec, gate_h8, level_order, bwd_fold;
+  int gate, chan_mintx, pool_tx, pool_cpt, r2_cpt, wsa_fat, chan_tx, chanf_tx, split_mlp, nt, half_vec, gate_h8, level_order, bwd_fold;
   int resident_wgs;        // MGACBAM_RESIDENT_WGS: override of the co-resident workgroup budget the hand-off eligibility is sized from
   int fault;               // MGACBAM_FAULT: fault injection for tests (args.cuh)
   unsigned spin_limit;     // MGACBAM_SPIN_LIMIT
@@ -131,7 +131,7 @@ static Knobs read_knobs() {
   k.pool_tx = env_int("MGACBAM_POOL_TX", 0); k.pool_cpt = env_int("MGACBAM_POOL_CPT", 0); k.chan_tx = env_int("MGACBAM_CHAN_TX", 0);
   k.nt = env_int("MGACBAM_NT", 1); k.half_vec = env_int("MGACBAM_HALF_VEC", 4); k.gate_h8 = env_int("MGACBAM_GATE_H8", 1);
   k.level_order = env_int("MGACBAM_LEVEL_ORDER", 1); k.bwd_fold = env_int("MGACBAM_BWD_FOLD", 1);
-  k.r2_cpt = env_int("MGACBAM_R2_CPT", 0); k.chanf_tx = env_int("MGACBAM_CHANF_TX", 0); k.split_mlp = env_int("MGACBAM_SPLIT_MLP", -1);
+  k.r2_cpt = env_int("MGACBAM_R2_CPT", 0); k.wsa_fat = env_int("MGACBAM_WSA_FAT", 0); k.chanf_tx = env_int("MGACBAM_CHANF_TX", 0); k.split_mlp = env_int("MGACBAM_SPLIT_MLP", -1);
   k.resident_wgs = env_int("MGACBAM_RESIDENT_WGS", 0); k.fault = env_int("MGACBAM_FAULT", 0);
   const int sl = env_int("MGACBAM_SPIN_LIMIT", 0);
   k.spin_limit = sl > 0 ? static_cast<unsigned>(sl) : (1u << 20);
@@ -617,6 +617,7 @@ static int backward_args(const mgacbam_bwd_level_t& L, BwdArgs& A, Sig& sig) {
   A.nt = chan_tiles(A.t, A.g.H, A.g.W, VEC);
   A.nconv = A.g.B * conv_tiles(A.t, A.g.H, A.g.W);
   A.nwsa = A.g.B * wsa_tiles(A.t, A.g.H, A.g.W);
+  A.nrole = A.nwsa;
   A.npg = params_blocks(A.g);
   A.ncg = 0;
   A.nflag = static_cast<int>(sync_flags(static_cast<size_t>(L.H) * L.W));
@@ -694,7 +695,31 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
       smem = std::max(smem, (64 + static_cast<size_t>(std::max(kPghLds, kBlock / lv[l].t.pool_tx))) * sizeof(float));
       if (fuse_wsa) smem = std::max(smem, wsa_smem(lv[l].t, sig.k));
     }
-    const int grid = fill([&](const BwdArgs& a) { return (fuse_wsa ? pad8(a.nwsa) : 0) + sweep_blocks(a, a.t.pool_tx, cpt); });
+    if (fuse_wsa && knobs().wsa_fat) {
+      // experiment (MGACBAM_WSA_FAT=1, off by default): as many dWsa roles as the streaming workgroups leave slots idle (config 2: 1792 of
+      // 2048), each working through several tiles, instead of one thin role per tile.  Measured at configs 2 and 3: no change (26.9-27.2 us
+      // either way) -- what the roles add to the launch (5.5 us over the role-free kernel) is not slot displacement
+      int slots = 0;
+#define RES_R22(CPTV) slots = resident_workgroups(k_bwd_reduce2<TT, VV, CPTV, true>, smem)
+#define RES_R2(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; DISPATCH_CPT(cpt, RES_R22); }
+      DISPATCH_T_VEC(sig.dtype, sig.vec, RES_R2);
+#undef RES_R2
+#undef RES_R22
+      long long streaming = 0, tiles = 0;
+      for (int l = 0; l < n; ++l) {
+        const int cpb = (kBlock / lv[l].t.pool_tx) * cpt;
+        streaming += static_cast<long long>(lv[l].g.B) * ((lv[l].g.C + cpb - 1) / cpb);
+        tiles += lv[l].nwsa;
+      }
+      const long long idle = slots - streaming;
+      if (idle >= 32 && idle < tiles) {
+        for (int l = 0; l < n; ++l) {
+          lv[l].nrole = static_cast<int>(std::max(1ll, std::min<long long>(lv[l].nwsa, idle * lv[l].nwsa / tiles)));
+          G.lv[l].nrole = lv[l].nrole;
+        }
+      }
+    }
+    const int grid = fill([&](const BwdArgs& a) { return (fuse_wsa ? pad8(a.nrole) : 0) + sweep_blocks(a, a.t.pool_tx, cpt); });
 #define CALL_R22(CPTV) if (fuse_wsa) LAUNCH((k_bwd_reduce2<TT, VV, CPTV, true>), grid, smem, st, G); else LAUNCH((k_bwd_reduce2<TT, VV, CPTV, false>), grid, smem, st, G)
 #define CALL_R2(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; DISPATCH_CPT(cpt, CALL_R22); }
     DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_R2);
