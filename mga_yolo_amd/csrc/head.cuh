@@ -62,6 +62,8 @@ struct HeadArgs {
   int nwg_out, out_hl_max;                     // k_head_out: workgroups (runs of kHeadOutPx pixels), LDS floats per staged channel (launch maximum)
   int nwg1, act_ppt, act_hl_max;               // k_head_bwd_act: pixel runs of the level, pixels per thread, LDS floats of the launch's longest run
   int ncb, nshare;                             // k_head_bwd_gw: channel blocks, pixel shares per block (= partial sets of dW1)
+  long long* trace;                            // MGACBAM_TRACE builds only (tools/trace_head.py), else nullptr
+  int trace_base;                              // first trace slot of the launch the level rides in
   int accum_gx;                                // MGAHEAD_BWD_ACCUM_GX: gx += W1^T g_z
 };
 
@@ -71,7 +73,9 @@ constexpr int kHeadLdsX = 4096;  // floats of LDS for the K-split reduction of k
 constexpr int kHeadJC = 4;       // k_head_bwd_act: hidden channels per workgroup (= one batch of z loads: every workgroup is one memory round trip deep)
 constexpr int kHeadCB = 64;      // k_head_bwd_gw: channels of x per workgroup (4 N tiles)
 constexpr int kHeadNStat = 12;   // per-channel partial sums of k_head_bwd_act: g_a, g_a*zhat, 9 taps of dW_h, db_h
-__device__ __forceinline__ float siluf(float a) { return a / (1.f + expf(-a)); }
+// SiLU on the streaming paths: v_exp_f32 + v_rcp_f32 (common.cuh: sigmoid_fast, relative error ~1e-6); the accurate expf and IEEE
+// division cost ~25 VALU slots per element and made k_head_out / k_head_bwd_act VALU-bound (a wave64 instruction takes 4 cycles)
+__device__ __forceinline__ float siluf(float a) { return a * sigmoid_fast(a); }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // The two pixel-parallel GEMMs:   FWD  z[b,j,px]  = sum_c W1[j,c] x[b,c,px]      (M = hid, K = C)          segmentation.py:81
@@ -117,6 +121,9 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
   const int ksteps = (K + 3) >> 2;
   const int kper = (ksteps + KW - 1) / KW;                      // this wave's share of the K steps: [kbeg, kend)
   const int kbeg = kwi * kper, kend = min(ksteps, kbeg + kper);
+  const int gid = A.trace_base + blockIdx.x;
+  TRACE_HWID(A.trace, gid);
+  TRACE_MARK(A.trace, gid, 0);                                  // start
 
   for (int mt0 = 0; mt0 < MT; mt0 += mblk) {
     const int mtn = min(mblk, MT - mt0);                        // tiles in this block
@@ -128,7 +135,7 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
     // K steps in batches of KU.  BOTH operands of a batch are requested before its first MFMA: the activations (16-B loads, 4 channels x
     // 256 B per wave-load) and the weights, read from global memory straight in the MFMA lane layout (W1 is <= 64 KB and shared by
     // every workgroup: L1 / L2 hits) -- no LDS staging, no barrier in the loop; a workgroup is one or two memory round trips deep.
-    constexpr int KU = GX ? 4 : 8;
+    constexpr int KU = (GX || MTW == 4) ? 4 : 8;                 // (MTW = 4 with 8 steps in flight needs 156 VGPRs: 2 workgroups per CU)
     for (int ks0 = kbeg; ks0 < kend; ks0 += KU) {
       float bv[KU][VEC], zq[GX ? KU : 1][VEC], aw[KU][MTW];
 #pragma unroll
@@ -177,6 +184,13 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
         }
       }
     }
+#ifdef MGACBAM_TRACE
+    { float tsum = 0.f;
+#pragma unroll
+      for (int t = 0; t < MTW; ++t) tsum += acc[t][0][0];
+      if (tsum == 1.2345e30f) s_x[0] = tsum; }                   // force the MFMA results before the stamp
+    TRACE_MARK(A.trace, gid, 2);                                // K loop done (operands arrived, MFMAs issued)
+#endif
     // ---- K split: sum the KW waves' accumulators (wave kwi = 0 keeps the result) ------------------------------------------------------
     if (KW > 1) {
 #pragma unroll
@@ -200,6 +214,7 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
         }
       }
     }
+    TRACE_MARK(A.trace, gid, 3);                                // K split summed
     // ---- epilogue of this M block -------------------------------------------------------------------------------------------
     float oldv[GX ? MTW : 1][GX ? 4 : 1][VEC];             // GX + accumulate: every old value is requested before the first store
     if (GX && A.accum_gx && kwi == 0) {
@@ -250,6 +265,12 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
       }
     }
   }
+#ifdef MGACBAM_TRACE
+  TRACE_MARK(A.trace, gid, 5);                                  // stores issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  TRACE_MARK(A.trace, gid, 10);                                 // stores complete
+#endif
   if (!GX && g.training) {                                      // tile sums of z and z^2 per output channel
     __syncthreads();
     float* part = A.c.part + static_cast<size_t>(wg) * 2 * g.hidp;
@@ -262,7 +283,7 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
 }
 
 template <typename T, int VEC, bool GX, int MTW>
-__global__ __launch_bounds__(kBlock) void k_head_gemm(const Group<HeadArgs> G) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MTW == 4 || GX) ? 3 : 4))) void k_head_gemm(const Group<HeadArgs> G) {
   extern __shared__ __align__(16) float smem[];
   int local;
   const int l = find_level(G, blockIdx.x, local);
@@ -338,13 +359,19 @@ __global__ __launch_bounds__(kBlock) void k_head_stats(const Group<HeadArgs> G) 
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int kHeadOutPx = 256;
 constexpr int kHeadJO = 4;
-template <typename T>
+// row length of one staged channel: the run, W+1 pixels either side, and the slack of starting on a 16-byte boundary
+__host__ __device__ inline int head_out_row(int W) { return (kHeadOutPx + 2 * (W + 1) + 3 + 3) & ~3; }
+template <typename T, int VEC>
 __device__ __forceinline__ void head_out_body(const HeadArgs& A, const int wg, float* smem) {
   const HeadGeo& g = A.g;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int per = (g.HW + kHeadOutPx - 1) / kHeadOutPx;
   const int b = wg / per, p0 = (wg - b * per) * kHeadOutPx;
-  const int halo = g.W + 1, HL = kHeadOutPx + 2 * halo;
+  const int halo = g.W + 1;
+  const int lo = VEC == 4 ? ((p0 - halo) & ~3) : p0 - halo;     // first staged pixel (may be negative); VEC = 4: H*W % 4 == 0, every 16-byte group is wholly inside or outside the sample
+  const int nel = (p0 + kHeadOutPx + halo - lo + VEC - 1) / VEC; // VEC-groups staged per channel
+  const int NQ = (nel + kWave - 1) / kWave;                     // ... per lane
+  const int HLs = A.out_hl_max;                                 // row stride in LDS (the launch's longest row)
   const int pt = p0 + 4 * lane;                                 // this lane's first pixel
   float ml[4], mr[4];                                           // 0 where the left / right tap would wrap around the row end
 #pragma unroll
@@ -353,42 +380,58 @@ __device__ __forceinline__ void head_out_body(const HeadArgs& A, const int wg, f
     ml[i] = x > 0 ? 1.f : 0.f; mr[i] = x < g.W - 1 ? 1.f : 0.f;
   }
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int gid = 24576 + blockIdx.x;
+  TRACE_HWID(A.trace, gid);
+  TRACE_MARK(A.trace, gid, 0);
   const float* zb = A.c.z + static_cast<size_t>(b) * g.hid * g.HW;
-  float* s_w = smem + static_cast<size_t>(wave) * kHeadJO * A.out_hl_max;    // this wave's staging area
+  float* s_w = smem + static_cast<size_t>(wave) * kHeadJO * HLs;  // this wave's staging area: written and read by this wave only
   const int cw = (g.hid + 3) >> 2;                              // channels per wave
   const int jlo = wave * cw, jhi = min(g.hid, jlo + cw);
-  const int npass = (cw + kHeadJO - 1) / kHeadJO;               // uniform over the workgroup
+  const int npass = (cw + kHeadJO - 1) / kHeadJO;
   for (int ps = 0; ps < npass; ++ps) {
     const int j0 = jlo + ps * kHeadJO;
     const int jn = max(0, min(kHeadJO, jhi - j0));
     const float* par0 = A.c.par + static_cast<size_t>(min(j0, g.hid - 1)) * kHeadPar;   // uniform per wave: scalar loads
-    __syncthreads();
-    const int total = jn * HL;
-    constexpr int SU = 14;                                      // loads in flight per lane while staging
-    for (int e0 = lane; e0 < total; e0 += kWave * SU) {
-      float zv[SU];
+    // stage: (channel, group) pairs in batches of SU loads per lane, all requested before the first is used; channel and group of a
+    // batch slot are wave-uniform (scalar registers), so the BatchNorm constants are scalar operands
+    constexpr int SU = VEC == 4 ? 8 : 16;
+    const int tot = jn * NQ;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (the previous pass's LDS reads are done before the rows are overwritten)
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < tot; base += SU) {
+      float zv[SU][VEC];
+      int jv[SU], qv[SU];
+      {
+        int jq = base / NQ, qq = base - jq * NQ;
 #pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        const int e = e0 + u * kWave;
-        const int jj = e / HL, r = e - jj * HL;
-        const int p = p0 - halo + r;
-        zv[u] = 0.f;
-        if (e < total && p >= 0 && p < g.HW) zv[u] = zb[static_cast<size_t>(j0 + jj) * g.HW + p];
+        for (int u = 0; u < SU; ++u) { jv[u] = jq; qv[u] = qq; if (++qq == NQ) { qq = 0; ++jq; } }
       }
 #pragma unroll
       for (int u = 0; u < SU; ++u) {
-        const int e = e0 + u * kWave;
-        if (e < total) {
-          const int jj = e / HL, r = e - jj * HL;
-          const int p = p0 - halo + r;
-          s_w[e] = (p >= 0 && p < g.HW) ? siluf(zv[u] * par0[jj * kHeadPar] + par0[jj * kHeadPar + 1]) : 0.f;
+        const int idx = qv[u] * kWave + lane, p = lo + idx * VEC;
+#pragma unroll
+        for (int r = 0; r < VEC; ++r) zv[u][r] = 0.f;
+        if (base + u < tot && idx < nel && p >= 0 && p < g.HW) load_vec<float, VEC>(zb + static_cast<size_t>(j0 + jv[u]) * g.HW + p, zv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int idx = qv[u] * kWave + lane, p = lo + idx * VEC;
+        if (base + u < tot && idx < nel) {
+          const float sc = par0[jv[u] * kHeadPar], sh = par0[jv[u] * kHeadPar + 1];
+          const bool inside = p >= 0 && p < g.HW;               // outside the sample: the conv's zero padding (of the ACTIVATION)
+          float o[VEC];
+#pragma unroll
+          for (int r = 0; r < VEC; ++r) o[r] = inside ? siluf(zv[u][r] * sc + sh) : 0.f;
+          store_vec<float, VEC>(s_w + jv[u] * HLs + idx * VEC, o);
         }
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (ps == 0) TRACE_MARK(A.trace, gid, 1);                    // first pass staged
     for (int jj = 0; jj < jn; ++jj) {
       const float* w = par0 + jj * kHeadPar + 4;                 // SGPR operands
-      const float* a = s_w + jj * HL + 4 * lane + halo;          // activation of pixel pt
+      const float* a = s_w + jj * HLs + (pt - lo);               // activation of pixel pt
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const float* row = a + (u - 1) * g.W - 1;
@@ -402,6 +445,7 @@ __device__ __forceinline__ void head_out_body(const HeadArgs& A, const int wg, f
     }
   }
   __syncthreads();                                              // the waves' channel shares meet (fixed order)
+  TRACE_MARK(A.trace, gid, 2);                                  // all passes done
   float* s_acc = smem;
   if (wave > 0) {
 #pragma unroll
@@ -410,21 +454,25 @@ __device__ __forceinline__ void head_out_body(const HeadArgs& A, const int wg, f
   __syncthreads();
   if (wave == 0) {
     const float bias = A.p.bh[0];
-    T* lo = static_cast<T*>(A.logits) + static_cast<size_t>(b) * g.HW;
+    T* lo_ = static_cast<T*>(A.logits) + static_cast<size_t>(b) * g.HW;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float v = ((acc[i] + s_acc[(4 + i) * kWave + lane]) + (s_acc[(8 + i) * kWave + lane] + s_acc[(12 + i) * kWave + lane])) + bias;
-      if (pt + i < g.HW) lo[pt + i] = from_f32<T>(v);
+      if (pt + i < g.HW) lo_[pt + i] = from_f32<T>(v);
     }
   }
+#ifdef MGACBAM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TRACE_MARK(A.trace, gid, 10);
+#endif
 }
 
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_head_out(const Group<HeadArgs> G) {
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void k_head_out(const Group<HeadArgs> G) {
   extern __shared__ __align__(16) float smem[];
   int local;
   const int l = find_level(G, blockIdx.x, local);
-  head_out_body<T>(G.lv[l], local, smem);
+  head_out_body<T, VEC>(G.lv[l], local, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -450,6 +498,9 @@ __device__ __forceinline__ void head_bwd_act_body(const HeadArgs& A, const int w
   const int halo = g.W + 1, HL = TP + 2 * halo;
   float* s_g = smem;                                            // [HL]
   float* s_red = smem + A.act_hl_max;                           // [4 waves][ZU][kHeadNStat], behind the longest run of the launch
+  const int gid = 32768 + blockIdx.x;
+  TRACE_HWID(A.trace, gid);
+  TRACE_MARK(A.trace, gid, 0);
   const T* gl = static_cast<const T*>(A.gl) + static_cast<size_t>(b) * g.HW;
   const float* gl2 = A.gl2 ? A.gl2 + static_cast<size_t>(b) * g.HW : nullptr;
   for (int i = tid; i < HL; i += kBlock) {
@@ -462,6 +513,7 @@ __device__ __forceinline__ void head_bwd_act_body(const HeadArgs& A, const int w
     s_g[i] = v;
   }
   __syncthreads();
+  TRACE_MARK(A.trace, gid, 1);                                  // g_logits staged
   float g9[PP][9];                                              // g9[i][u*3+v] = g(y-u+1, x-v+1) of pixel i
   bool in[PP];
 #pragma unroll
@@ -506,7 +558,7 @@ __device__ __forceinline__ void head_bwd_act_body(const HeadArgs& A, const int w
             const float z = zq[jj][i];
             const float zh = (z - pr[2]) * pr[3];
             const float a = z * pr[0] + pr[1];
-            const float sg = 1.f / (1.f + expf(-a));
+            const float sg = sigmoid_fast(a);
             const float sv = a * sg;
             float gs = 0.f;
 #pragma unroll
@@ -528,6 +580,7 @@ __device__ __forceinline__ void head_bwd_act_body(const HeadArgs& A, const int w
       }
     }
     __syncthreads();
+    TRACE_MARK(A.trace, gid, 2);                                // channels done (z loaded, g_a stores issued, wave sums)
     for (int i = tid; i < jn * kHeadNStat; i += kBlock) {
       float sum = 0.f;
       for (int w = 0; w < 4; ++w) sum += s_red[w * ZU * kHeadNStat + i];
@@ -535,6 +588,10 @@ __device__ __forceinline__ void head_bwd_act_body(const HeadArgs& A, const int w
     }
     __syncthreads();
   }
+#ifdef MGACBAM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TRACE_MARK(A.trace, gid, 10);
+#endif
 }
 
 template <typename T>

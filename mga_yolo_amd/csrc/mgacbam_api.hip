@@ -1128,6 +1128,7 @@ static int head_common(const mgahead_params_t& P, int B, int C, int H, int W, in
                 reinterpret_cast<float*>(cp + L.par), reinterpret_cast<float*>(cp + L.part)};
   A.tile_px = t.tile_px; A.tiles_per_sample = t.tps; A.nwg = t.nwg;
   A.gx_tile_px = t.gx_tile_px; A.gx_tiles_per_sample = t.gx_tps; A.fw_kw = t.fw_kw; A.gx_kw = t.gx_kw; A.fw_mtw = t.fw_mtw; A.gx_mtw = t.gx_mtw;
+  A.trace = knobs().trace; A.trace_base = 0;
   A.nwg_out = t.nwg_out; A.nwg1 = t.nwg1; A.act_ppt = t.act_ppt; A.act_hl_max = t.act_hl; A.ncb = t.ncb; A.nshare = t.nshare;
   sig = Sig{dtype, t.vec, 0, 0, 0, 0};
   return 0;
@@ -1164,6 +1165,7 @@ static int head_forward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t s
         }
       if (!Gm.n) continue;
       Gm.start[Gm.n] = grid;
+      for (int l = 0; l < Gm.n; ++l) Gm.lv[l].trace_base = pass * 8192;
       for (int l = 0; l < Gm.n; ++l) {                            // the wave arrangement follows the template the level runs under
         int pw;
         head_waves(Gm.lv[l].g.hidp / 16, mtw, Gm.lv[l].g.C, pw, Gm.lv[l].fw_kw);
@@ -1186,15 +1188,17 @@ static int head_forward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t s
   }
   {
     int ohl = 0;
-    for (int l = 0; l < n; ++l) ohl = std::max(ohl, kHeadOutPx + 2 * (lv[l].g.W + 1));
+    for (int l = 0; l < n; ++l) ohl = std::max(ohl, head_out_row(lv[l].g.W));
     for (int l = 0; l < n; ++l) { lv[l].out_hl_max = ohl; G.lv[l].out_hl_max = ohl; }
     const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.nwg_out; });
     const size_t smem = std::max(static_cast<size_t>(4) * kHeadJO * ohl, static_cast<size_t>(16) * kWave) * sizeof(float);
+#define CALL_HO(Tt) { if (sig.vec == 4) { LAUNCH((k_head_out<Tt, 4>), grid, smem, st, G); } else { LAUNCH((k_head_out<Tt, 1>), grid, smem, st, G); } }
     switch (sig.dtype) {
-      case MGACBAM_F32: LAUNCH(k_head_out<float>, grid, smem, st, G); break;
-      case MGACBAM_F16: LAUNCH(k_head_out<__half>, grid, smem, st, G); break;
-      default: LAUNCH(k_head_out<bf16_t>, grid, smem, st, G); break;
+      case MGACBAM_F32: CALL_HO(float); break;
+      case MGACBAM_F16: CALL_HO(__half); break;
+      default: CALL_HO(bf16_t); break;
     }
+#undef CALL_HO
     if (int e = launch_status("k_head_out")) return e;
   }
   return 0;
@@ -1240,6 +1244,7 @@ static int head_backward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t 
     if (int e = launch_status("k_head_bwd_fin")) return e;
   }
   {
+    for (int l = 0; l < n; ++l) G.lv[l].trace_base = 16384;
     const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.g.B * a.gx_tiles_per_sample; });
     const size_t smem = head_gemm_smem(lv, n);
 #define CALL_HX(Tt, Vv) LAUNCH((k_head_gemm<Tt, Vv, true, 2>), grid, smem, st, G)

@@ -20,8 +20,8 @@ def main(path, only_f32=True):
         if d in seen:
             continue
         seen.add(d)
-        print("%-66s vgpr=%4s sgpr=%4s scratch=%4s occ=%s lds=%s" % (
-            d, g("VGPRs"), g("SGPRs"), g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]"),
+        print("%-66s vgpr=%4s agpr=%3s sgpr=%4s scratch=%4s occ=%s lds=%s" % (
+            d, g("VGPRs"), g("AGPRs"), g("TotalSGPRs"), g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]"),
             g(r"LDS Size \[bytes/block\]")))
 
 
