@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MGACBAM_ABI_VERSION 12
+#define MGACBAM_ABI_VERSION 13
 #define MGACBAM_MAX_LEVELS 8          /* P3/P4/P5 need 3 */
 
 enum { MGACBAM_F32 = 0, MGACBAM_F16 = 1, MGACBAM_BF16 = 2 };
@@ -329,7 +329,7 @@ enum { MGAHEAD_BWD_ACCUM_GX = 1 };
 
 size_t mgahead_ctx_bytes(int B, int C, int H, int W, int hidden);
 size_t mgahead_bwd_scratch_bytes(int B, int C, int H, int W, int hidden);
-int mgahead_forward(const mgahead_fwd_level_t* levels, int n_levels, void* stream);     /* 3 launches for all levels */
+int mgahead_forward(const mgahead_fwd_level_t* levels, int n_levels, void* stream);     /* 4 launches for all levels (the 1x1-conv GEMM in two: one-tile levels, the rest) */
 int mgahead_backward(const mgahead_bwd_level_t* levels, int n_levels, void* stream);    /* 5 launches for all levels */
 
 /* Kendall multi-task combine of MGAModel.loss (mga_yolo/model/model.py:204-206), on the device so that no loss value has to visit
@@ -339,6 +339,17 @@ int mgahead_backward(const mgahead_bwd_level_t* levels, int n_levels, void* stre
 int mgakendall_forward(const float* det, int n_det, const float* seg, const float* log_vars, float* total, void* stream);
 int mgakendall_backward(const float* det, int n_det, const float* seg, const float* log_vars, const float* g_total,
                         float* g_det, float* g_seg, float* g_log_vars, void* stream);
+
+/* The loss tail of MGAModel.loss in one piece (model.py:196-206): mgaseg_forward followed by the combine on its total, and the backward
+ * of both -- same results as the two calls, with the combine riding in the loss's last forward launch / its backward launch (two
+ * launches fewer per step; every one of these kernels is launch-latency-bound).  `out` = mgaseg_forward's out (1 + 3 * n_levels floats;
+ * out[0] = the seg total the combine reads).  Backward: levels[l].glogits <- d total.sum-weighted / d logits_l, g_det[n_det],
+ * g_log_vars[2]; g_seg (dL/d seg total) may be NULL. */
+int mgaseg_kendall_forward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, void* ws, float* out,
+                           const float* det, int n_det, const float* log_vars, float* total, void* stream);
+int mgaseg_kendall_backward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, const void* ws, const float* out,
+                            const float* det, int n_det, const float* log_vars, const float* g_total,
+                            float* g_det, float* g_seg, float* g_log_vars, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * ProbMaskGater: mga_yolo/nn/modules/probmaskgater.py:58-98, training mode, 'gumbel' (hard = 0) and 'hard_st'

@@ -8,7 +8,7 @@ import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGACBAM_LIB") or os.path.join(_PKG, "libmgacbam.so")   # MGACBAM_LIB: A/B builds in tuning sweeps
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_LEVELS = 8
 F32, F16, BF16 = 0, 1, 2
 # stage bit masks (include/mgacbam.h)
@@ -135,6 +135,8 @@ SYMBOLS = {
     "mgahead_backward": (C.c_int, [C.POINTER(HeadBwdLevel), C.c_int, C.c_void_p]),
     "mgakendall_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgakendall_backward": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 7),
+    "mgaseg_kendall_forward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgaseg_kendall_backward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6),
     "mgapmg_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_size_t, C.POINTER(PmgCfg), C.c_void_p]),
     "mgapmg_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_size_t, C.POINTER(PmgCfg), C.c_void_p]),
 }

@@ -303,6 +303,18 @@ __global__ __launch_bounds__(kBlock) void k_head_stats(const Group<HeadArgs> G) 
   const HeadGeo& g = A.g;
   const int tid = threadIdx.x, which = tid & 1, gq = tid >> 1;  // workgroup = one hidden channel: 2 sums x 128 strides over the tiles
   const int j = local;
+  // everything thread 0 needs for the tail is requested NOW, beside the partials (after the reduction each load would be a round trip
+  // of its own: the stores to the running statistics between them keep the compiler from batching)
+  float rm0 = 0.f, rv0 = 0.f, gam = 0.f, bet = 0.f, whv[9];
+  long long nbt0 = 0;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) whv[q] = 0.f;
+  if (tid == 0) {
+    rm0 = A.p.rmean[j]; rv0 = A.p.rvar[j]; gam = A.p.gamma[j]; bet = A.p.beta[j];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) whv[q] = A.p.wh[static_cast<size_t>(j) * 9 + q];
+    if (j == 0 && A.p.nbt && g.training) nbt0 = *A.p.nbt;
+  }
   double acc = 0.0;
   if (g.training) {
     const float* p = A.c.part + static_cast<size_t>(which) * g.hidp + j;
@@ -332,19 +344,20 @@ __global__ __launch_bounds__(kBlock) void k_head_stats(const Group<HeadArgs> G) 
       if (v < 0.0) v = 0.0;
       mean = static_cast<float>(m); var = static_cast<float>(v);
       const double unb = n > 1.0 ? v * n / (n - 1.0) : v;
-      A.p.rmean[j] = (1.f - g.momentum) * A.p.rmean[j] + g.momentum * mean;
-      A.p.rvar[j] = (1.f - g.momentum) * A.p.rvar[j] + g.momentum * static_cast<float>(unb);
-      if (j == 0 && A.p.nbt) *A.p.nbt += 1;
+      A.p.rmean[j] = (1.f - g.momentum) * rm0 + g.momentum * mean;
+      A.p.rvar[j] = (1.f - g.momentum) * rv0 + g.momentum * static_cast<float>(unb);
+      if (j == 0 && A.p.nbt) *A.p.nbt = nbt0 + 1;
     } else {
-      mean = A.p.rmean[j]; var = A.p.rvar[j];
+      mean = rm0; var = rv0;
     }
     const float rstd = 1.0f / sqrtf(var + g.eps);
     A.c.mean[j] = mean;
     A.c.rstd[j] = rstd;
     float* par = A.c.par + static_cast<size_t>(j) * kHeadPar;
-    const float sc = A.p.gamma[j] * rstd;
-    par[0] = sc; par[1] = A.p.beta[j] - mean * sc; par[2] = mean; par[3] = rstd;
-    for (int q = 0; q < 9; ++q) par[4 + q] = A.p.wh[static_cast<size_t>(j) * 9 + q];
+    const float sc = gam * rstd;
+    par[0] = sc; par[1] = bet - mean * sc; par[2] = mean; par[3] = rstd;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) par[4 + q] = whv[q];
   }
 }
 
@@ -612,6 +625,8 @@ __global__ __launch_bounds__(kBlock) void k_head_bwd_fin(const Group<HeadArgs> G
   const HeadGeo& g = A.g;
   const int tid = threadIdx.x, s = tid & 15, gq = tid >> 4;
   const int j = local;
+  float rstd0 = 0.f, gam0 = 0.f, mean0 = 0.f;                   // thread 0's tail operands, requested beside the partials
+  if (tid == 0) { rstd0 = A.c.rstd[j]; gam0 = A.p.gamma[j]; mean0 = A.c.mean[j]; }
   double acc = 0.0;
   if (s < kHeadNStat) {
     const float* p = A.s.part1 + static_cast<size_t>(j) * kHeadNStat + s;
@@ -641,10 +656,9 @@ __global__ __launch_bounds__(kBlock) void k_head_bwd_fin(const Group<HeadArgs> G
     A.gbeta[j] = gb; A.ggamma[j] = gg;
     for (int q = 0; q < 9; ++q) A.gwh[static_cast<size_t>(j) * 9 + q] = static_cast<float>(red[0][2 + q]);
     if (j == 0) A.gbh[0] = static_cast<float>(red[0][11]);
-    const float rstd = A.c.rstd[j];
-    A.s.kst[j] = A.p.gamma[j] * rstd;
-    A.s.kst[g.hidp + j] = A.c.mean[j];
-    A.s.kst[2 * g.hidp + j] = rstd;
+    A.s.kst[j] = gam0 * rstd0;
+    A.s.kst[g.hidp + j] = mean0;
+    A.s.kst[2 * g.hidp + j] = rstd0;
     A.s.kst[3 * g.hidp + j] = g.training ? static_cast<float>(red[0][0] / n) : 0.f;
     A.s.kst[4 * g.hidp + j] = g.training ? static_cast<float>(red[0][1] / n) : 0.f;
   }
@@ -766,36 +780,41 @@ __global__ __launch_bounds__(kBlock) void k_head_bwd_gw(const Group<HeadArgs> G)
   head_bwd_gw_body<T, VEC>(G.lv[l], local, smem);
 }
 
-// k_head_bwd_gwf: dW1[j,c] = sum over the pixel shares: workgroup = 64 outputs x 4 share strides (8 loads in flight each), then a
-//   fixed-order combine through LDS
+// k_head_bwd_gwf: dW1[j,c] = sum over the pixel shares: workgroup = 32 outputs x 8 share strides, up to 16 loads in flight per thread
+//   (256 shares = two round trips), then a fixed-order combine through LDS
+constexpr int kHeadGwfOut = 32;
 __global__ __launch_bounds__(kBlock) void k_head_bwd_gwf(const Group<HeadArgs> G) {
   __shared__ float red[kBlock];
   int local;
   const int l = find_level(G, blockIdx.x, local);
   const HeadArgs& A = G.lv[l];
   const HeadGeo& g = A.g;
-  const int tid = threadIdx.x, o = tid & 63, q = tid >> 6;
-  const int idx = local * 64 + o;
+  constexpr int NS = kBlock / kHeadGwfOut;                      // share strides
+  const int tid = threadIdx.x, o = tid % kHeadGwfOut, q = tid / kHeadGwfOut;
+  const int idx = local * kHeadGwfOut + o;
   float s = 0.f;
   if (idx < g.hid * g.C) {
     const int j = idx / g.C, c = idx - j * g.C;
     const int cb = c / kHeadCB, cc = c - cb * kHeadCB;
     const float* p = A.s.gwpart + (static_cast<size_t>(cb) * A.nshare * g.hidp + j) * kHeadCB + cc;
     const size_t stride = static_cast<size_t>(g.hidp) * kHeadCB;
-    constexpr int U = 8;
-    int w = q;
-    for (; w + (U - 1) * 4 < A.nshare; w += U * 4) {
+    constexpr int U = 16;
+    for (int w0 = q; w0 < A.nshare; w0 += U * NS) {
       float v[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = p[(w + u * 4) * stride];
+      for (int u = 0; u < U; ++u) { const int w = w0 + u * NS; v[u] = w < A.nshare ? p[w * stride] : 0.f; }
 #pragma unroll
       for (int u = 0; u < U; ++u) s += v[u];
     }
-    for (; w < A.nshare; w += 4) s += p[w * stride];
   }
   red[tid] = s;
   __syncthreads();
-  if (q == 0 && idx < g.hid * g.C) A.gw1[idx] = (red[o] + red[64 + o]) + (red[128 + o] + red[192 + o]);
+  if (q == 0 && idx < g.hid * g.C) {
+    float t = red[o];
+#pragma unroll
+    for (int w = 1; w < NS; ++w) t += red[w * kHeadGwfOut + o];
+    A.gw1[idx] = t;
+  }
 }
 
 }  // namespace mgacbam

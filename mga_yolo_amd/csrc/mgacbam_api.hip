@@ -991,15 +991,16 @@ static int seg_args(const mgaseg_level_t* levels, int n, const mgaseg_cfg_t* cfg
   A.start[n] = tot;
   A.w_bce = cfg->bce_weight; A.w_dice = cfg->dice_weight; A.smooth = cfg->smooth; A.lambda = cfg->loss_lambda;
   A.ufl = cfg->use_unified_focal ? 1 : 0; A.u_lambda = cfg->ufl_lambda; A.u_delta = cfg->ufl_delta; A.u_gamma = cfg->ufl_gamma;
-  A.out = nullptr; A.gout = nullptr;
+  A.out = nullptr; A.gout = nullptr; A.has_kd = 0; memset(&A.kd, 0, sizeof(A.kd));
   return tot;
 }
-extern "C" int mgaseg_forward(const mgaseg_level_t* levels, int n, const mgaseg_cfg_t* cfg, void* ws, float* out, void* stream) {
+static int seg_forward_impl(const mgaseg_level_t* levels, int n, const mgaseg_cfg_t* cfg, void* ws, float* out, const KendallArgs* kd, void* stream) {
   if (int e = seg_check(levels, n, cfg, false)) return e;
   if (!ws || !out) return fail(MGACBAM_E_NULL, "segloss: ws / out is NULL");
   SegArgs A;
   const int grid = seg_args(levels, n, cfg, ws, A);
   A.out = out;
+  if (kd) { A.has_kd = 1; A.kd = *kd; }
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (levels[0].dtype) {
     case MGACBAM_F32: LAUNCH(k_seg_partial<float>, grid, 0, st, A); break;
@@ -1012,12 +1013,13 @@ extern "C" int mgaseg_forward(const mgaseg_level_t* levels, int n, const mgaseg_
   g_err[0] = 0;
   return 0;
 }
-extern "C" int mgaseg_backward(const mgaseg_level_t* levels, int n, const mgaseg_cfg_t* cfg, const void* ws, const float* gout, void* stream) {
+static int seg_backward_impl(const mgaseg_level_t* levels, int n, const mgaseg_cfg_t* cfg, const void* ws, const float* gout, const KendallArgs* kd, void* stream) {
   if (int e = seg_check(levels, n, cfg, true)) return e;
-  if (!ws || !gout) return fail(MGACBAM_E_NULL, "segloss: ws / gout is NULL");
+  if (!ws || (!gout && !kd)) return fail(MGACBAM_E_NULL, "segloss: ws / gout is NULL");
   SegArgs A;
   const int grid = seg_args(levels, n, cfg, const_cast<void*>(ws), A);
   A.gout = gout;
+  if (kd) { A.has_kd = 1; A.kd = *kd; }
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (levels[0].dtype) {
     case MGACBAM_F32: LAUNCH(k_seg_bwd<float>, grid, 0, st, A); break;
@@ -1027,6 +1029,32 @@ extern "C" int mgaseg_backward(const mgaseg_level_t* levels, int n, const mgaseg
   if (int e = launch_status("k_seg_bwd")) return e;
   g_err[0] = 0;
   return 0;
+}
+extern "C" int mgaseg_forward(const mgaseg_level_t* levels, int n, const mgaseg_cfg_t* cfg, void* ws, float* out, void* stream) {
+  return seg_forward_impl(levels, n, cfg, ws, out, nullptr, stream);
+}
+extern "C" int mgaseg_backward(const mgaseg_level_t* levels, int n, const mgaseg_cfg_t* cfg, const void* ws, const float* gout, void* stream) {
+  return seg_backward_impl(levels, n, cfg, ws, gout, nullptr, stream);
+}
+static int kendall_check(const float* det, int n_det, const float* log_vars) {
+  if (!det || !log_vars) return fail(MGACBAM_E_NULL, "kendall: NULL pointer");
+  if (n_det < 1 || n_det > 4096) return fail(MGACBAM_E_SHAPE, "kendall: n_det=%d", n_det);
+  return 0;
+}
+extern "C" int mgaseg_kendall_forward(const mgaseg_level_t* levels, int n, const mgaseg_cfg_t* cfg, void* ws, float* out,
+                                      const float* det, int n_det, const float* log_vars, float* total, void* stream) {
+  if (int e = kendall_check(det, n_det, log_vars)) return e;
+  if (!total) return fail(MGACBAM_E_NULL, "kendall: total is NULL");
+  const KendallArgs kd{det, out, log_vars, nullptr, total, nullptr, nullptr, nullptr, n_det};
+  return seg_forward_impl(levels, n, cfg, ws, out, &kd, stream);
+}
+extern "C" int mgaseg_kendall_backward(const mgaseg_level_t* levels, int n, const mgaseg_cfg_t* cfg, const void* ws, const float* out,
+                                       const float* det, int n_det, const float* log_vars, const float* g_total,
+                                       float* g_det, float* g_seg, float* g_log_vars, void* stream) {
+  if (int e = kendall_check(det, n_det, log_vars)) return e;
+  if (!out || !g_total || !g_det || !g_log_vars) return fail(MGACBAM_E_NULL, "kendall: NULL pointer");
+  const KendallArgs kd{det, out, log_vars, g_total, nullptr, g_det, g_seg, g_log_vars, n_det};
+  return seg_backward_impl(levels, n, cfg, ws, nullptr, &kd, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1266,7 +1294,7 @@ static int head_backward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t 
     if (int e = launch_status("k_head_bwd_gw")) return e;
   }
   {
-    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return (a.g.hid * a.g.C + 63) / 64; });
+    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return (a.g.hid * a.g.C + kHeadGwfOut - 1) / kHeadGwfOut; });
     LAUNCH(k_head_bwd_gwf, grid, 0, st, G);
     if (int e = launch_status("k_head_bwd_gwf")) return e;
   }

@@ -26,6 +26,12 @@ struct SegLevel {
   float w_scale;
   int bilinear;         // target resize rule when (Ht,Wt) != (H,W): 0 nearest (segmentation.py:110), 1 bilinear align_corners=False (:103-108)
 };
+// Kendall multi-task combine (mga_yolo/model/model.py:204-206): total[i] = e^{-s0} det[i] + s0 + e^{-s1} seg + s1
+struct KendallArgs {
+  const float* det; const float* seg; const float* log_vars; const float* g_total;
+  float* total; float* g_det; float* g_seg; float* g_log_vars;
+  int n;
+};
 struct SegArgs {
   int n;
   int start[kSegMaxLevels + 1];     // workgroup ids of level l: [start[l], start[l+1])
@@ -34,7 +40,9 @@ struct SegArgs {
   int ufl;                          // 1: Unified Focal mode (segmentation.py:44-85, 114-131): slot 0 of the sums = modified focal CE
   float u_lambda, u_delta, u_gamma;
   float* out;                       // [0] total, then per level {bce, dice, combined}
-  const float* gout;                // backward: dL/d(total), device scalar
+  const float* gout;                // backward: dL/d(total), device scalar (has_kd: unused, dL/d(seg total) comes from the combine)
+  int has_kd;                       // mgaseg_kendall_*: the Kendall combine rides in k_seg_final / k_seg_bwd (two launches fewer per step)
+  KendallArgs kd;
 };
 
 __device__ __forceinline__ float seg_target(const SegLevel& L, int b, int y, int x) {
@@ -94,20 +102,30 @@ __global__ __launch_bounds__(kBlock) void k_seg_partial(const SegArgs A) {
   }
 }
 
-// one workgroup: per-sample sums (fixed order), the level terms and the total
+// one workgroup: per-sample sums (fixed order), the level terms and the total.  Wave w owns level w (kSegMaxLevels = waves per
+// workgroup): the levels' chains of dependent loads run side by side and the sums over the samples are wave reductions (no barrier);
+// the operands of the Kendall epilogue are requested at the start.
 __global__ __launch_bounds__(kBlock) void k_seg_final(const SegArgs A) {
-  __shared__ float red[8];
-  float total = 0.f;
-  for (int l = 0; l < A.n; ++l) {
+  static_assert(kSegMaxLevels <= kBlock / kWave, "one wave per level");
+  __shared__ float s_comb[kSegMaxLevels];
+  __shared__ float s_total;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float s0 = 0.f, s1 = 0.f;
+  if (A.has_kd) { s0 = A.kd.log_vars[0]; s1 = A.kd.log_vars[1]; }
+  if (wave < A.n) {
+    const int l = wave;
     const SegLevel& L = A.lv[l];
     float bce = 0.f, dice = 0.f;
-    for (int b = threadIdx.x; b < L.B; b += kBlock) {
+    for (int b = lane; b < L.B; b += kWave) {
+      float pv[kSegParts][4];
+#pragma unroll
+      for (int p = 0; p < kSegParts; ++p) load_vec<float, 4>(L.part + (static_cast<size_t>(b) * kSegParts + p) * 4, pv[p]);
       float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
       for (int p = 0; p < kSegParts; ++p)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s[q] += L.part[(static_cast<size_t>(b) * kSegParts + p) * 4 + q];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) L.sums[b * 4 + q] = s[q];
+        for (int q = 0; q < 4; ++q) s[q] += pv[p][q];
+      store_vec<float, 4>(L.sums + b * 4, s);
       bce += s[0];
       if (A.ufl) {                                                             // _lmft, segmentation.py:65-76 (tp + fn = T, tp + fp = P)
         const float den = fmaxf(A.u_delta * s[3] + (1.f - A.u_delta) * s[2] + A.smooth, kSegEps);
@@ -116,18 +134,29 @@ __global__ __launch_bounds__(kBlock) void k_seg_final(const SegArgs A) {
         dice += 1.f - (2.f * s[1] + A.smooth) / (s[2] + s[3] + A.smooth);      // segmentation.py:38-42
       }
     }
-    bce = block_sum(bce, threadIdx.x, red);
-    dice = block_sum(dice, threadIdx.x, red);
-    if (threadIdx.x == 0) {
+    bce = wave_group_sum(bce, kWave);
+    dice = wave_group_sum(dice, kWave);
+    if (lane == 0) {
       bce /= static_cast<float>(L.B) * static_cast<float>(L.H * L.W);          // BCEWithLogitsLoss(reduction="mean")
       dice /= static_cast<float>(L.B);
       const float comb = A.ufl ? L.w_scale * (A.u_lambda * bce + (1.f - A.u_lambda) * dice)      // segmentation.py:120
                                : L.w_scale * (A.w_bce * bce + A.w_dice * dice);                  // segmentation.py:134-136
       A.out[1 + 3 * l] = bce; A.out[2 + 3 * l] = dice; A.out[3 + 3 * l] = comb;
-      total += comb;
+      s_comb[l] = comb;
     }
   }
-  if (threadIdx.x == 0) A.out[0] = total * A.lambda;                           // segmentation.py:149
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float total = 0.f;
+    for (int l = 0; l < A.n; ++l) total += s_comb[l];                          // level order
+    A.out[0] = total * A.lambda;                                               // segmentation.py:149
+    s_total = total * A.lambda;
+  }
+  if (A.has_kd) {                                                              // model.py:204-206 on the value just formed
+    __syncthreads();
+    const float seg_term = expf(-s1) * s_total + s1, e0 = expf(-s0);
+    for (int i = threadIdx.x; i < A.kd.n; i += kBlock) A.kd.total[i] = e0 * A.kd.det[i] + s0 + seg_term;
+  }
 }
 
 template <typename T>
@@ -142,7 +171,31 @@ __global__ __launch_bounds__(kBlock) void k_seg_bwd(const SegArgs A) {
   const int HW = L.H * L.W;
   const T* xp = static_cast<const T*>(L.logits) + static_cast<size_t>(b) * HW;
   T* gp = static_cast<T*>(L.glogits) + static_cast<size_t>(b) * HW;
-  const float g = *A.gout * A.lambda * L.w_scale;
+  float gout;
+  if (A.has_kd) {                                               // dL/d(seg total) = e^{-s1} sum_i g_total[i]: every wave forms it for itself (no barrier);
+    const int lane = threadIdx.x & 63;                          // workgroup 0 also leaves the combine's own gradients
+    const float s0 = A.kd.log_vars[0], s1 = A.kd.log_vars[1], seg = *A.kd.seg;
+    const float e0 = expf(-s0), e1 = expf(-s1);
+    const bool writer = blockIdx.x == 0 && threadIdx.x < kWave;
+    float gsum = 0.f, g0 = 0.f;
+    for (int i = lane; i < A.kd.n; i += kWave) {
+      const float gi = A.kd.g_total[i];
+      if (writer) A.kd.g_det[i] = gi * e0;
+      gsum += gi;
+      g0 += gi * (1.f - e0 * A.kd.det[i]);
+    }
+    gsum = wave_group_sum(gsum, kWave);                          // (uniform: every lane holds the sum)
+    g0 = wave_group_sum(g0, kWave);
+    if (writer && lane == 0) {
+      if (A.kd.g_seg) *A.kd.g_seg = gsum * e1;
+      A.kd.g_log_vars[0] = g0;
+      A.kd.g_log_vars[1] = gsum * (1.f - e1 * seg);
+    }
+    gout = gsum * e1;
+  } else {
+    gout = *A.gout;
+  }
+  const float g = gout * A.lambda * L.w_scale;
   const float I = L.sums[b * 4 + 1], D = L.sums[b * 4 + 2] + L.sums[b * 4 + 3] + A.smooth;
   const float kb = g * A.w_bce / (static_cast<float>(L.B) * static_cast<float>(HW));
   const float kd = g * A.w_dice / static_cast<float>(L.B);
@@ -183,12 +236,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_bwd(const SegArgs A) {
   }
 }
 
-// Kendall multi-task combine (mga_yolo/model/model.py:204-206): total[i] = e^{-s0} det[i] + s0 + e^{-s1} seg + s1.  One wave.
-struct KendallArgs {
-  const float* det; const float* seg; const float* log_vars; const float* g_total;
-  float* total; float* g_det; float* g_seg; float* g_log_vars;
-  int n;
-};
+// mgakendall_*: the combine alone, one wave
 __global__ __launch_bounds__(kWave) void k_kendall_fwd(const KendallArgs A) {
   const float s0 = A.log_vars[0], s1 = A.log_vars[1];
   const float seg_term = expf(-s1) * *A.seg + s1;

@@ -7,7 +7,7 @@
     feeds both), accumulated in the head's GEMM epilogue instead of a feature-sized add.
 
 Everything between the neck's P3/P4/P5 features and the Detect head's inputs -- i.e. every MGA-specific layer of the reference model
-plus its loss terms -- runs as C-ABI calls on pre-allocated buffers: 3 + 2 + 2 + 1 launches forward, 1 + 1 + 3 + 5 backward for
+plus its loss terms -- runs as C-ABI calls on pre-allocated buffers: 4 + 2 + 2 launches forward, 1 + 3 + 5 backward for
 all three levels together, recorded into one hipGraph.  The backbone / neck / Detect / detection loss are out of scope:
 their contribution enters as given tensors -- `gy_l` (dL/d refined_l, what Detect's backward would deliver) and `det_loss`
 (the criterion's 3-vector).
@@ -112,18 +112,17 @@ class SlicePlan:
         st = self._stream()
         _lib.check(self.lib.mgahead_forward(self._hf, self.n, st), "mgahead_forward")                 # features -> mask logits
         self.cbam.forward()                                                                            # [feature, logits] -> refined
-        _lib.check(self.lib.mgaseg_forward(self._seg, self.n, C.byref(self._seg_cfg), self.seg_ws.data_ptr(), self.seg_out.data_ptr(), st),
-                   "mgaseg_forward")                                                                   # logits, targets -> seg_total (+ log entries)
-        _lib.check(self.lib.mgakendall_forward(self.det_loss.data_ptr(), 3, self.seg_out.data_ptr(), self.log_vars.data_ptr(),
-                                               self.total.data_ptr(), st), "mgakendall_forward")
+        # logits, targets -> seg_total (+ log entries) -> Kendall total, the combine riding in the loss's last launch
+        _lib.check(self.lib.mgaseg_kendall_forward(self._seg, self.n, C.byref(self._seg_cfg), self.seg_ws.data_ptr(), self.seg_out.data_ptr(),
+                                                   self.det_loss.data_ptr(), 3, self.log_vars.data_ptr(), self.total.data_ptr(), st),
+                   "mgaseg_kendall_forward")
 
     def backward(self):
         st = self._stream()
-        _lib.check(self.lib.mgakendall_backward(self.det_loss.data_ptr(), 3, self.seg_out.data_ptr(), self.log_vars.data_ptr(),
-                                                self.g_total.data_ptr(), self.g_det.data_ptr(), self.g_seg.data_ptr(),
-                                                self.g_log_vars.data_ptr(), st), "mgakendall_backward")
-        _lib.check(self.lib.mgaseg_backward(self._seg, self.n, C.byref(self._seg_cfg), self.seg_ws.data_ptr(), self.g_seg.data_ptr(), st),
-                   "mgaseg_backward")                                                                  # -> seg_glogits
+        _lib.check(self.lib.mgaseg_kendall_backward(self._seg, self.n, C.byref(self._seg_cfg), self.seg_ws.data_ptr(), self.seg_out.data_ptr(),
+                                                    self.det_loss.data_ptr(), 3, self.log_vars.data_ptr(), self.g_total.data_ptr(),
+                                                    self.g_det.data_ptr(), self.g_seg.data_ptr(), self.g_log_vars.data_ptr(), st),
+                   "mgaseg_kendall_backward")                                                          # -> seg_glogits, g_det, g_log_vars
         self.cbam.backward()                                                                           # gy -> gx (MaskCBAM's part), dL/dmask (its part of dL/dlogits)
         _lib.check(self.lib.mgahead_backward(self._hb, self.n, st), "mgahead_backward")                # gx += head's part; head parameter gradients
 
@@ -140,5 +139,5 @@ class SlicePlan:
         return self.shapes[0][0]
 
     def launches(self) -> dict:
-        return dict(forward="3 (heads) + 2 (MaskCBAM) + 2 (seg loss) + 1 (Kendall)",
-                    backward="1 (Kendall) + 1 (seg loss) + 3 (MaskCBAM) + 5 (heads)")
+        return dict(forward="4 (heads) + 2 (MaskCBAM) + 2 (seg loss + Kendall)",
+                    backward="1 (seg loss + Kendall) + 3 (MaskCBAM) + 5 (heads)")

@@ -272,3 +272,50 @@ def test_device_kendall_combine(built_lib, tag):
     det2, seg2, lv2 = (t.detach().clone().requires_grad_(True) for t in (det, seg, lv))
     kendall_combine(det2, seg2, lv2).sum().backward()
     assert torch.allclose(lv2.grad.cpu(), torch.from_numpy(z["g_log_vars"]), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ufl", [0, 1])
+def test_fused_loss_tail_equals_the_two_calls_bit_for_bit(built_lib, ufl):
+    """mgaseg_kendall_forward / _backward (the combine riding in the loss's own launches) against mgaseg_* followed by mgakendall_*,
+    through the C-ABI on the same buffers: total, every log entry, dL/dlogits of every level, g_det, g_seg, g_log_vars."""
+    import ctypes as C
+    from mga_yolo_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    B, sizes = 5, [(24, 20), (12, 10), (6, 5)]
+    logits = [torch.randn(B, 1, h, w, generator=g).cuda() for h, w in sizes]
+    targets = [(torch.rand(B, 1, 48, 40, generator=g) > 0.7).float().cuda() for _ in sizes]
+    det = torch.tensor([1.3, 0.4, 2.2]).cuda(); lv = torch.tensor([0.3, -0.2]).cuda(); g_total = torch.tensor([1.0, -0.5, 2.0]).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(fused):
+        n = len(sizes)
+        levels = (_lib.SegLevel * n)()
+        gl = [torch.zeros_like(x) for x in logits]
+        for l, (h, w) in enumerate(sizes):
+            S = levels[l]
+            S.logits, S.target, S.glogits = logits[l].data_ptr(), targets[l].data_ptr(), gl[l].data_ptr()
+            S.B, S.H, S.W, S.Ht, S.Wt, S.dtype, S.scale_weight, S.resize = B, h, w, 48, 40, _lib.F32, (1.0, 0.5, 0.25)[l], _lib.SEG_NEAREST
+        cfg = _lib.SegCfg(1.0, 1.0, 1.0, 0.7, ufl, 0.5, 0.6, 0.5)
+        ws = torch.zeros(lib.mgaseg_ws_bytes(levels, n), dtype=torch.uint8, device="cuda")
+        out = torch.zeros(1 + 3 * n, device="cuda"); total = torch.zeros(3, device="cuda")
+        g_det = torch.zeros(3, device="cuda"); g_seg = torch.zeros((), device="cuda"); g_lv = torch.zeros(2, device="cuda")
+        if fused:
+            _lib.check(lib.mgaseg_kendall_forward(levels, n, C.byref(cfg), ws.data_ptr(), out.data_ptr(), det.data_ptr(), 3, lv.data_ptr(),
+                                                  total.data_ptr(), st), "fwd")
+            _lib.check(lib.mgaseg_kendall_backward(levels, n, C.byref(cfg), ws.data_ptr(), out.data_ptr(), det.data_ptr(), 3, lv.data_ptr(),
+                                                   g_total.data_ptr(), g_det.data_ptr(), g_seg.data_ptr(), g_lv.data_ptr(), st), "bwd")
+        else:
+            _lib.check(lib.mgaseg_forward(levels, n, C.byref(cfg), ws.data_ptr(), out.data_ptr(), st), "fwd")
+            _lib.check(lib.mgakendall_forward(det.data_ptr(), 3, out.data_ptr(), lv.data_ptr(), total.data_ptr(), st), "kfwd")
+            _lib.check(lib.mgakendall_backward(det.data_ptr(), 3, out.data_ptr(), lv.data_ptr(), g_total.data_ptr(), g_det.data_ptr(),
+                                               g_seg.data_ptr(), g_lv.data_ptr(), st), "kbwd")
+            _lib.check(lib.mgaseg_backward(levels, n, C.byref(cfg), ws.data_ptr(), g_seg.data_ptr(), st), "bwd")
+        torch.cuda.synchronize()
+        return [out, total, g_det, g_seg.reshape(1), g_lv] + gl
+
+    for a, b in zip(run(True), run(False)):
+        assert torch.equal(a, b)
+    # NULL g_seg is allowed in the fused backward; a NULL total is not
+    assert lib.mgaseg_kendall_forward(None, 3, None, None, None, det.data_ptr(), 3, lv.data_ptr(), None, st) != 0
