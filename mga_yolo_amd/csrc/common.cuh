@@ -108,8 +108,15 @@ __device__ __forceinline__ bool isclosef_(float a, float b) { return fabsf(a - b
 // S0+S1 in lane 31 and the wave's total in lane 63, which v_readlane hands to every lane.
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_add(float v) {
-  // lanes whose row is masked out (or whose source is invalid) receive `old` = 0
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+  // lanes whose row is masked out (or whose source is invalid) receive `old` = 0.  Full row mask (the in-row steps: every lane has a
+  // valid source): bound_ctrl set, which is what lets the compiler fold the move into ONE v_add_f32_dpp -- with bound_ctrl clear it
+  // emits v_mov 0 + v_mov_dpp + v_add per step (GCNDPPCombine needs an undefined `old` for float adds)
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF));
+}
+// a value every lane reads from the same address, kept in a scalar register from here on (the compiler does not use scalar loads for
+// memory the kernel may also write, and re-issues vector loads wherever a store could alias: request such constants once, up front)
+__device__ __forceinline__ float uniform_load(const float* p) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *p)));
 }
 __device__ __forceinline__ float wave_group_sum(float v, int width) {
   if (width >= 2) v = dpp_add<0xB1>(v);                         // quad_perm [1,0,3,2]

@@ -118,8 +118,14 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
   const T* xb = GX ? nullptr : static_cast<const T*>(A.x) + static_cast<size_t>(b) * g.C * g.HW + pxo;
   const float* gab = GX ? A.s.ga + static_cast<size_t>(b) * g.hid * g.HW + pxo : nullptr;
   const float* zb = A.c.z + static_cast<size_t>(b) * g.hid * g.HW + pxo;
-  const int ksteps = (K + 3) >> 2;
-  const int kper = (ksteps + KW - 1) / KW;                      // this wave's share of the K steps: [kbeg, kend)
+  // forward with C % 4 == 0: the K order inside a group of 4 steps (16 channels) is permuted so that a lane's weights of the group are
+  // 4 CONSECUTIVE floats of a W1 row -- lane (lk, ln) at step 4q + r takes channel 16q + 4lk + r -- one 16-byte load instead of four
+  // gathers of 16 cache lines each (those made the TA, not HBM, the limit of the levels with long K); groups are whole per wave
+  const bool wperm = !GX && (g.C & 3) == 0;
+  const int ksteps = wperm ? ((K + 15) >> 4) << 2 : (K + 3) >> 2;
+  int kper_ = (ksteps + KW - 1) / KW;                           // this wave's share of the K steps: [kbeg, kend)
+  if (wperm) kper_ = (kper_ + 3) & ~3;
+  const int kper = kper_;
   const int kbeg = kwi * kper, kend = min(ksteps, kbeg + kper);
   const int gid = A.trace_base + blockIdx.x;
   TRACE_HWID(A.trace, gid);
@@ -138,6 +144,28 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
     constexpr int KU = (GX || MTW == 4) ? 4 : 8;                 // (MTW = 4 with 8 steps in flight needs 156 VGPRs: 2 workgroups per CU)
     for (int ks0 = kbeg; ks0 < kend; ks0 += KU) {
       float bv[KU][VEC], zq[GX ? KU : 1][VEC], aw[KU][MTW];
+      if (wperm) {
+#pragma unroll
+        for (int gi = 0; gi < KU / 4; ++gi) {
+          const int kk0 = ((ks0 >> 2) + gi) * 16 + 4 * lk;      // this lane's 4 channels of the group
+          const bool gok = ks0 + 4 * gi < kend && kk0 < K;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) bv[4 * gi + r][q] = 0.f;
+            if (gok && px_ok) load_vec<T, VEC>(xb + static_cast<size_t>(kk0 + r) * g.HW, bv[4 * gi + r]);
+          }
+#pragma unroll
+          for (int t = 0; t < MTW; ++t) {
+            const int mt = mw * MTW + t;
+            const int out = (mt0 + mt) * 16 + ln;
+            float w4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (gok && mt < mtn && out < M) load_vec<float, 4>(A.p.w1 + static_cast<size_t>(out) * g.C + kk0, w4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) aw[4 * gi + r][t] = w4[r];
+          }
+        }
+      } else {
 #pragma unroll
       for (int u = 0; u < KU; ++u) {
         const int kk = (ks0 + u) * 4 + lk;                      // this lane's k channel
@@ -162,6 +190,7 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
           if (kok && mt < mtn && out < M)
             aw[u][t] = GX ? A.p.w1[static_cast<size_t>(kk) * g.C + out] : A.p.w1[static_cast<size_t>(out) * g.C + kk];
         }
+      }
       }
 #pragma unroll
       for (int u = 0; u < KU; ++u) {
@@ -404,7 +433,14 @@ __device__ __forceinline__ void head_out_body(const HeadArgs& A, const int wg, f
   for (int ps = 0; ps < npass; ++ps) {
     const int j0 = jlo + ps * kHeadJO;
     const int jn = max(0, min(kHeadJO, jhi - j0));
-    const float* par0 = A.c.par + static_cast<size_t>(min(j0, g.hid - 1)) * kHeadPar;   // uniform per wave: scalar loads
+    float pc[kHeadJO][2 + 9];                                   // BatchNorm scale / shift and the 3x3 weights of the pass's channels: scalar registers
+#pragma unroll
+    for (int jj = 0; jj < kHeadJO; ++jj) {
+      const float* pr = A.c.par + static_cast<size_t>(min(j0 + jj, g.hid - 1)) * kHeadPar;
+      pc[jj][0] = uniform_load(pr); pc[jj][1] = uniform_load(pr + 1);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) pc[jj][2 + q] = uniform_load(pr + 4 + q);
+    }
     // stage: (channel, group) pairs in batches of SU loads per lane, all requested before the first is used; channel and group of a
     // batch slot are wave-uniform (scalar registers), so the BatchNorm constants are scalar operands
     constexpr int SU = VEC == 4 ? 8 : 16;
@@ -430,7 +466,10 @@ __device__ __forceinline__ void head_out_body(const HeadArgs& A, const int wg, f
       for (int u = 0; u < SU; ++u) {
         const int idx = qv[u] * kWave + lane, p = lo + idx * VEC;
         if (base + u < tot && idx < nel) {
-          const float sc = par0[jv[u] * kHeadPar], sh = par0[jv[u] * kHeadPar + 1];
+          float sc = pc[0][0], sh = pc[0][1];                   // (jv is wave-uniform: scalar selects)
+#pragma unroll
+          for (int jj = 1; jj < kHeadJO; ++jj)
+            if (jv[u] == jj) { sc = pc[jj][0]; sh = pc[jj][1]; }
           const bool inside = p >= 0 && p < g.HW;               // outside the sample: the conv's zero padding (of the ACTIVATION)
           float o[VEC];
 #pragma unroll
@@ -442,8 +481,10 @@ __device__ __forceinline__ void head_out_body(const HeadArgs& A, const int wg, f
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     if (ps == 0) TRACE_MARK(A.trace, gid, 1);                    // first pass staged
-    for (int jj = 0; jj < jn; ++jj) {
-      const float* w = par0 + jj * kHeadPar + 4;                 // SGPR operands
+#pragma unroll
+    for (int jj = 0; jj < kHeadJO; ++jj) {
+      if (jj >= jn) break;                                      // uniform
+      const float* w = pc[jj] + 2;                               // SGPR operands
       const float* a = s_w + jj * HLs + (pt - lo);               // activation of pixel pt
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
@@ -510,7 +551,7 @@ __device__ __forceinline__ void head_bwd_act_body(const HeadArgs& A, const int w
   const int b = wg / per, p0 = (wg - b * per) * TP;
   const int halo = g.W + 1, HL = TP + 2 * halo;
   float* s_g = smem;                                            // [HL]
-  float* s_red = smem + A.act_hl_max;                           // [4 waves][ZU][kHeadNStat], behind the longest run of the launch
+  float* s_red = smem + A.act_hl_max;                           // [16 lane rows][ZU][kHeadNStat], behind the longest run of the launch
   const int gid = 32768 + blockIdx.x;
   TRACE_HWID(A.trace, gid);
   TRACE_MARK(A.trace, gid, 0);
@@ -534,13 +575,14 @@ __device__ __forceinline__ void head_bwd_act_body(const HeadArgs& A, const int w
     const int p = p0 + tid + i * kBlock;
     in[i] = i < ppt && p < g.HW;
     const int x = p % g.W;
-    const float m_lo = x > 0 ? 1.f : 0.f, m_hi = x < g.W - 1 ? 1.f : 0.f;   // g(.., x-1) / g(.., x+1) exist
+    const float m_in = in[i] ? 1.f : 0.f;                        // pixels past the run / the sample: every tap 0, so they add nothing to any sum
+    const float m_lo = x > 0 ? m_in : 0.f, m_hi = x < g.W - 1 ? m_in : 0.f;   // g(.., x-1) / g(.., x+1) exist
     const float* c = s_g + (i < ppt ? tid + i * kBlock : tid) + halo;
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const float* row = c + (1 - u) * g.W;                     // row y - u + 1
       g9[i][u * 3 + 0] = m_hi * row[1];                          // v = 0: x + 1
-      g9[i][u * 3 + 1] = row[0];
+      g9[i][u * 3 + 1] = m_in * row[0];
       g9[i][u * 3 + 2] = m_lo * row[-1];                         // v = 2: x - 1
     }
   }
@@ -557,17 +599,35 @@ __device__ __forceinline__ void head_bwd_act_body(const HeadArgs& A, const int w
         zq[jj][i] = 0.f;
         if (jj < jn && in[i]) zq[jj][i] = zb[static_cast<size_t>(j0 + jj) * g.HW + p0 + tid + i * kBlock];
       }
+#ifdef MGACBAM_TRACE
+    { float tsum = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < ZU; ++jj)
+#pragma unroll
+        for (int i = 0; i < PP; ++i) tsum += zq[jj][i];
+      if (tsum == 1.2345e30f) s_g[0] = tsum; }
+    TRACE_MARK(A.trace, gid, 3);                                // z arrived
+#endif
+    // the channels' constants (BatchNorm scale / shift / mean / rstd, 3x3 weights) into scalar registers, once: read inside the pixel
+    // loop they were vector loads re-issued after every g_a store (possible alias), 16 dependent round trips per thread
+    float pc[ZU][4 + 9];
+#pragma unroll
+    for (int jj = 0; jj < ZU; ++jj) {
+      const float* pr = A.c.par + static_cast<size_t>(min(j0 + jj, g.hid - 1)) * kHeadPar;
+#pragma unroll
+      for (int q = 0; q < 13; ++q) pc[jj][q] = uniform_load(pr + q);
+    }
 #pragma unroll
     for (int jj = 0; jj < ZU; ++jj) {
       if (jj < jn) {                                            // uniform
         const int j = j0 + jj;
-        const float* pr = A.c.par + static_cast<size_t>(j) * kHeadPar;   // uniform address: scalar loads, SGPR operands
+        const float* pr = pc[jj];
         float r[kHeadNStat];
 #pragma unroll
         for (int q = 0; q < kHeadNStat; ++q) r[q] = 0.f;
 #pragma unroll
         for (int i = 0; i < PP; ++i) {
-          if (in[i]) {
+          if (i < ppt) {                                        // uniform; lanes past the sample run with g9 = 0 and z = 0 (g_a = 0, sums unchanged)
             const float z = zq[jj][i];
             const float zh = (z - pr[2]) * pr[3];
             const float a = z * pr[0] + pr[1];
@@ -577,26 +637,29 @@ __device__ __forceinline__ void head_bwd_act_body(const HeadArgs& A, const int w
 #pragma unroll
             for (int q = 0; q < 9; ++q) gs += pr[4 + q] * g9[i][q];
             const float ga = gs * (sg * (1.f + a * (1.f - sg)));
-            gab[static_cast<size_t>(j) * g.HW + p0 + tid + i * kBlock] = ga;
+            if (in[i]) gab[static_cast<size_t>(j) * g.HW + p0 + tid + i * kBlock] = ga;
             r[0] += ga; r[1] += ga * zh;
 #pragma unroll
             for (int q = 0; q < 9; ++q) r[2 + q] += sv * g9[i][q];
             if (j == 0) r[11] += g9[i][4];
           }
         }
+        // sums over the 16 lanes of a DPP row only (4 one-instruction steps per value); the 16 rows of the workgroup meet in LDS below
 #pragma unroll
-        for (int q = 0; q < kHeadNStat; ++q) r[q] = wave_group_sum(r[q], kWave);
-        if (lane == 0) {
+        for (int q = 0; q < kHeadNStat; ++q) r[q] = wave_group_sum(r[q], 16);
+        if ((lane & 15) == 0) {
 #pragma unroll
-          for (int q = 0; q < kHeadNStat; ++q) s_red[(wave * ZU + jj) * kHeadNStat + q] = r[q];
+          for (int q = 0; q < kHeadNStat; ++q) s_red[((wave * 4 + (lane >> 4)) * ZU + jj) * kHeadNStat + q] = r[q];
         }
       }
     }
+    TRACE_MARK(A.trace, gid, 4);                                // wave 0: channels done (g_a stores issued, row sums)
     __syncthreads();
-    TRACE_MARK(A.trace, gid, 2);                                // channels done (z loaded, g_a stores issued, wave sums)
+    TRACE_MARK(A.trace, gid, 2);                                // all waves there
     for (int i = tid; i < jn * kHeadNStat; i += kBlock) {
       float sum = 0.f;
-      for (int w = 0; w < 4; ++w) sum += s_red[w * ZU * kHeadNStat + i];
+#pragma unroll
+      for (int w = 0; w < 16; ++w) sum += s_red[w * ZU * kHeadNStat + i];       // fixed order: lane row 0..15
       part[static_cast<size_t>(j0) * kHeadNStat + i] = sum;
     }
     __syncthreads();

@@ -1083,7 +1083,7 @@ static HeadTiling head_tiling(int B, int C, int H, int W, int hidden) {
   t.vec = (HW % 4 == 0) ? 4 : 1;
   t.hidp = (hidden + 15) & ~15; t.cp = (C + 15) & ~15;
   int pw;
-  t.fw_mtw = t.hidp / 16 >= 2 ? 4 : 1;                              // forward: hidden <= 16 runs under the one-tile template (light workgroups), the rest under the 4-tile one
+  t.fw_mtw = t.hidp / 16 > 8 ? 4 : 2;                               // forward: two accumulator tiles per wave (120 VGPRs, 4 workgroups per CU, every level of a YOLOv8n/s call in ONE launch); hidden > 128: four
   t.gx_mtw = 2;                                                     // gx: its B operand (g_a, z: E/4 each) is cheap to re-read; light workgroups
   head_waves(t.hidp / 16, t.fw_mtw, C, pw, t.fw_kw);
   t.tile_px = pw * 16 * t.vec;
@@ -1178,16 +1178,15 @@ static int head_forward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t s
   G.n = n;
   for (int l = 0; l < n; ++l) G.lv[l] = lv[l];
   {
-    // two launches at most: the levels that need ONE accumulator tile per wave (hidden <= 16: the largest feature map, whose workgroups
-    // should stay light) and the rest together (template = their largest need); each level alone is latency-bound, so levels that can
-    // share a launch overlap each other
+    // one launch per accumulator template (two tiles per wave: hidden <= 128, i.e. every level of the n/s models; four beyond): each level
+    // alone is latency-bound, so levels that share a launch overlap each other
     const size_t smem = head_gemm_smem(lv, n);
     for (int pass = 0; pass < 2; ++pass) {
       Group<HeadArgs> Gm;
       Gm.n = 0;
       int grid = 0, mtw = 1;
       for (int l = 0; l < n; ++l)
-        if ((lv[l].fw_mtw == 1) == (pass == 0)) {
+        if ((lv[l].fw_mtw <= 2) == (pass == 0)) {
           Gm.lv[Gm.n] = lv[l]; Gm.start[Gm.n] = grid; grid += lv[l].nwg; ++Gm.n;
           mtw = std::max(mtw, lv[l].fw_mtw);
         }
@@ -1200,7 +1199,7 @@ static int head_forward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t s
         if (pw * 16 * sig.vec != Gm.lv[l].tile_px) return fail(MGACBAM_E_SHAPE, "mask head: inconsistent tiling");   // (cannot happen: see head_tiling)
       }
 #define CALL_HP3(Tt, Vv, Mm) LAUNCH((k_head_gemm<Tt, Vv, false, Mm>), grid, smem, st, Gm)
-#define CALL_HP(Tt, Vv) { if (mtw == 1) { CALL_HP3(Tt, Vv, 1); } else if (mtw == 2) { CALL_HP3(Tt, Vv, 2); } else { CALL_HP3(Tt, Vv, 4); } }
+#define CALL_HP(Tt, Vv) { if (mtw <= 2) { CALL_HP3(Tt, Vv, 2); } else { CALL_HP3(Tt, Vv, 4); } }
       if (sig.dtype == MGACBAM_F32) { if (sig.vec == 4) { CALL_HP(float, 4); } else { CALL_HP(float, 1); } }
       else if (sig.dtype == MGACBAM_F16) { if (sig.vec == 4) { CALL_HP(__half, 4); } else { CALL_HP(__half, 1); } }
       else { if (sig.vec == 4) { CALL_HP(bf16_t, 4); } else { CALL_HP(bf16_t, 1); } }
@@ -1258,7 +1257,7 @@ static int head_backward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t 
     for (int l = 0; l < n; ++l) hl = std::max(hl, lv[l].act_hl_max);
     for (int l = 0; l < n; ++l) { lv[l].act_hl_max = hl; G.lv[l].act_hl_max = hl; }      // the reduction scratch sits behind the launch's longest run
     const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.nwg1 * ((a.g.hid + kHeadJC - 1) / kHeadJC); });
-    const size_t smem = (static_cast<size_t>(hl) + 4 * 4 * kHeadNStat) * sizeof(float);
+    const size_t smem = (static_cast<size_t>(hl) + 16 * kHeadJC * kHeadNStat) * sizeof(float);
     switch (sig.dtype) {
       case MGACBAM_F32: LAUNCH(k_head_bwd_act<float>, grid, smem, st, G); break;
       case MGACBAM_F16: LAUNCH(k_head_bwd_act<__half>, grid, smem, st, G); break;

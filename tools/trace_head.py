@@ -42,7 +42,7 @@ os.environ["MGACBAM_TRACE_PTR"] = ""; _lib.reload_env()
 t = buf.cpu().numpy().reshape(-1, 16)
 NAMES = {"gemm": ((0, "start"), (2, "K loop done"), (3, "K split summed"), (5, "stores issued"), (10, "stores complete")),
          "out": ((0, "start"), (1, "first pass staged"), (2, "all passes done"), (10, "end")),
-         "act": ((0, "start"), (1, "g_logits staged"), (2, "channels done"), (10, "end"))}
+         "act": ((0, "start"), (1, "g_logits staged"), (3, "z arrived"), (4, "wave 0 channels done"), (2, "all waves done"), (10, "end"))}
 for base, name, kind in ((0, "fwd gemm pass 0 (one-tile levels)", "gemm"), (8192, "fwd gemm pass 1", "gemm"), (16384, "gx", "gemm"),
                          (24576, "k_head_out", "out"), (32768, "k_head_bwd_act", "act")):
     tt = t[base:base + 8192]
