@@ -753,8 +753,12 @@ __device__ __forceinline__ void head_bwd_gw_body(const HeadArgs& A, const int wg
   const long long total = static_cast<long long>(g.B) * nch;
   float* s_kst = smem;                                          // [5][hidp]
   float* s_acc = smem + 5 * g.hidp;                             // [4 waves][16 x 16 tile] staging for the cross-wave sum
+  const int gid = 40960 + blockIdx.x;
+  TRACE_HWID(A.trace, gid);
+  TRACE_MARK(A.trace, gid, 0);
   for (int i = tid; i < 5 * g.hidp; i += kBlock) s_kst[i] = A.s.kst[i];
   __syncthreads();
+  TRACE_MARK(A.trace, gid, 1);                                  // constants staged
   float* outp = A.s.gwpart + static_cast<size_t>(wg) * g.hidp * kHeadCB;
   for (int mt0 = 0; mt0 < MT; mt0 += kHeadMTW) {
     const int mtn = min(kHeadMTW, MT - mt0);
@@ -770,7 +774,10 @@ __device__ __forceinline__ void head_bwd_gw_body(const HeadArgs& A, const int wg
       kj[t] = s_kst[j]; mean[t] = s_kst[g.hidp + j]; rstd[t] = s_kst[2 * g.hidp + j]; gbn[t] = s_kst[3 * g.hidp + j]; ggn[t] = s_kst[4 * g.hidp + j];
     }
     // two pixel chunks per trip: both chunks' loads are issued before the first MFMA (a chunk per memory round trip would leave each
-    // wave a chain of dependent latencies)
+    // wave a chain of dependent latencies).  Measured and left alone (cfg2, 47-48 us, 152 MB fetched = 3.1 TB/s): more shares (1024), 3-4
+    // chunks per trip for the levels with few hidden tiles, two hidden tiles per pass at 3 waves per SIMD, longest-chain level first,
+    // register double buffering -- none moved it by more than +-2 us; H ADJACENT chunks per wave (instead of across the 4 waves) cost
+    // +10 us.  The 64-byte-per-row-and-instruction footprint of the MFMA operand layout (4 lanes share a channel row) is what is left.
     const long long stride = 4ll * A.nshare;
     for (long long ch0 = static_cast<long long>(share) * 4 + wave; ch0 < total; ch0 += 2 * stride) {
       float av[2][kHeadMTW][VEC], bv[2][NT][VEC];
@@ -817,6 +824,10 @@ __device__ __forceinline__ void head_bwd_gw_body(const HeadArgs& A, const int wg
         }
       }
     }
+#ifdef MGACBAM_TRACE
+    if (acc[0][0][0] == 1.2345e30f) s_acc[0] = 0.f;
+    TRACE_MARK(A.trace, gid, 2);                                // wave 0: pixel loop done
+#endif
     // cross-wave sum, one 16 x 16 tile at a time (fixed order: wave 0..3); D layout: lane l, register v: row 4*(l/16)+v, column l%16
 #pragma unroll
     for (int t = 0; t < kHeadMTW; ++t) {
@@ -833,6 +844,10 @@ __device__ __forceinline__ void head_bwd_gw_body(const HeadArgs& A, const int wg
       }
     }
   }
+#ifdef MGACBAM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TRACE_MARK(A.trace, gid, 10);
+#endif
 }
 
 template <typename T, int VEC>

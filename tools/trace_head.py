@@ -25,7 +25,7 @@ for l, (B, C, H, W) in enumerate(shapes):
 for _ in range(3):
     plan.step()
 torch.cuda.synchronize()
-buf = torch.zeros(5 * 8192 * 16, dtype=torch.int64, device="cuda")
+buf = torch.zeros(6 * 8192 * 16, dtype=torch.int64, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 if which == "fwd":
     plan.cbam.backward()                                        # the predecessor of the head forward in step order
@@ -42,9 +42,10 @@ os.environ["MGACBAM_TRACE_PTR"] = ""; _lib.reload_env()
 t = buf.cpu().numpy().reshape(-1, 16)
 NAMES = {"gemm": ((0, "start"), (2, "K loop done"), (3, "K split summed"), (5, "stores issued"), (10, "stores complete")),
          "out": ((0, "start"), (1, "first pass staged"), (2, "all passes done"), (10, "end")),
+         "gw": ((0, "start"), (1, "constants staged"), (2, "wave 0 pixel loop done"), (10, "end")),
          "act": ((0, "start"), (1, "g_logits staged"), (3, "z arrived"), (4, "wave 0 channels done"), (2, "all waves done"), (10, "end"))}
 for base, name, kind in ((0, "fwd gemm pass 0 (one-tile levels)", "gemm"), (8192, "fwd gemm pass 1", "gemm"), (16384, "gx", "gemm"),
-                         (24576, "k_head_out", "out"), (32768, "k_head_bwd_act", "act")):
+                         (24576, "k_head_out", "out"), (32768, "k_head_bwd_act", "act"), (40960, "k_head_bwd_gw", "gw")):
     tt = t[base:base + 8192]
     tt = tt[tt[:, 0] > 0]
     if not len(tt):
