@@ -24,28 +24,29 @@ def main():
     buf = torch.zeros(nblk * 16, dtype=torch.int64, device="cuda")
     which = sys.argv[1] if len(sys.argv) > 1 else "fwd"       # fwd: k_gate, bwd: k_bwd_apply
     NAMES = {"fwd": NAMES_FWD, "bwd": NAMES_BWD, "pool": NAMES_POOL}[which]
-    S = __import__("mga_yolo_amd")._lib.BWD_STAGES
+    L = __import__("mga_yolo_amd")._lib
+    S = L.BWD_STAGES
     for _ in range(3):
         plan.forward(); plan.backward()
     torch.cuda.synchronize()
     if which == "fwd":
         plan.forward(1)
         torch.cuda.synchronize()
-        os.environ["MGACBAM_TRACE_PTR"] = str(buf.data_ptr())
+        os.environ["MGACBAM_TRACE_PTR"] = str(buf.data_ptr()); L.reload_env()
         plan.forward(6)
     elif which == "pool":
         plan.backward()
         torch.cuda.synchronize()
-        os.environ["MGACBAM_TRACE_PTR"] = str(buf.data_ptr())
+        os.environ["MGACBAM_TRACE_PTR"] = str(buf.data_ptr()); L.reload_env()
         plan.forward(1)
     else:
         plan.forward()
         plan.backward(S["reduce1"]); plan.backward(S["convT"]); plan.backward(S["reduce2"] | S["wsa"] | 64)
         torch.cuda.synchronize()
-        os.environ["MGACBAM_TRACE_PTR"] = str(buf.data_ptr())
+        os.environ["MGACBAM_TRACE_PTR"] = str(buf.data_ptr()); L.reload_env()
         plan.backward(S["params"] | S["apply"] | 64)
     torch.cuda.synchronize()
-    os.environ["MGACBAM_TRACE_PTR"] = ""
+    os.environ["MGACBAM_TRACE_PTR"] = ""; L.reload_env()
     t = buf.cpu().numpy().reshape(nblk, 16)
     used = t[:, 0] > 0
     ids = np.nonzero(used)[0]
