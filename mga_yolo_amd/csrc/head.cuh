@@ -3,13 +3,13 @@
 //       z = Conv1x1(x)  (hid x C GEMM per pixel, no bias)  ->  BatchNorm2d (batch statistics in training)  ->  SiLU  ->  Conv3x3 + bias
 //   layer-loop hand-off: mga_yolo/model/model.py:57-74 (the logits go to MaskCBAM as `mask` and to the segmentation loss)
 //
-// forward  (3 launches)  k_head_proj    x (1 read)   -> z (B,hid,HW) fp32 + per-workgroup partial sums of z, z^2           [MFMA fp32 16x16x4]
+// forward  (3 launches)  k_head_gemm<F> x (1 read)   -> z (B,hid,HW) fp32 + per-workgroup partial sums of z, z^2           [MFMA fp32 16x16x4]
 //                        k_head_stats   partials     -> mean, rstd (+ running statistics, num_batches_tracked)               [tiny]
 //                        k_head_out     z            -> s = SiLU(gamma*zhat+beta), staged with a 1-px halo in LDS -> 3x3 conv -> logits
 // backward (5 launches)  k_head_bwd_act z, g_logits  -> g_a (B,hid,HW) = convT3x3(g) * SiLU'(a); partials of sum g_a, sum g_a*zhat,
 //                                                        dW_h (9 taps), db_h
 //                        k_head_bwd_fin partials     -> dgamma, dbeta, dW_h, db_h and the per-channel constants of g_z
-//                        k_head_bwd_gx  g_a, z       -> g_z on the fly -> gx = W1^T g_z  (1 write)                              [MFMA]
+//                        k_head_gemm<X> g_a, z       -> g_z on the fly -> gx (+)= W1^T g_z  (1 write, 1 read when accumulating)  [MFMA]
 //                        k_head_bwd_gw  g_a, z, x    -> partials of dW1 = sum_px g_z x^T  (x: 1 read)                            [MFMA]
 //                        k_head_bwd_gwf partials     -> dW1
 // One launch covers every level of the call (P3+P4+P5), as everywhere in this library.
@@ -67,8 +67,8 @@ struct HeadArgs {
   int accum_gx;                                // MGAHEAD_BWD_ACCUM_GX: gx += W1^T g_z
 };
 
-constexpr int kHeadMTW = 4;      // upper bound of the 16-output tiles a wave accumulates at once (template MTW = 1, 2, 4: 16 registers x VEC/4... each;
-                                 // the forward takes min(4, tiles of the level) so that x is read once, gx takes 2: its B operand is small and cheap to re-read)
+constexpr int kHeadMTW = 4;      // upper bound of the 16-output tiles a wave accumulates at once (template MTW = 2 or 4: 16 registers x VEC/4... each;
+                                 // forward: 2 up to hidden = 128 (every level of a call in one launch, 4 workgroups per CU), 4 beyond; gx: 2)
 constexpr int kHeadLdsX = 4096;  // floats of LDS for the K-split reduction of k_head_gemm (4 waves x VEC x 4 registers x 64 lanes)
 constexpr int kHeadJC = 4;       // k_head_bwd_act: hidden channels per workgroup (= one batch of z loads: every workgroup is one memory round trip deep)
 constexpr int kHeadCB = 64;      // k_head_bwd_gw: channels of x per workgroup (4 N tiles)
@@ -84,8 +84,9 @@ __device__ __forceinline__ float siluf(float a) { return a * sigmoid_fast(a); }
 //   lane l: k l/16, group l%16), D 16 x 16 in 4 registers (lane l, register v: output 4*(l/16)+v, group l%16).  With VEC = 4 a lane loads
 //   16 B = 4 consecutive pixels of its k-channel (a wave-load = 4 channels x 256 B contiguous) and register r of that vector is the B
 //   operand of sub-tile r: 64 pixels per wave and K step; VEC = 1 (H*W % 4 != 0): one dword per lane, 16 pixels per wave.
-//   Workgroup = 4 waves = MW (along M) x KW (along K) x PW (along pixels); M in blocks of 16*kHeadMTW*MW outputs.  The weights are
-//   read from global memory directly in the A layout, batch by batch together with the activations (no LDS staging, no barriers).
+//   Workgroup = 4 waves = MW (along M) x KW (along K) x PW (along pixels); M in blocks of 16*MTW*MW outputs.  The weights are
+//   read from global memory directly in the A layout, batch by batch together with the activations (no LDS staging, no barriers);
+//   forward: as 16-byte loads, the K order permuted inside each group of 16 channels (see wperm below).
 // ---------------------------------------------------------------------------------------------------------------------------
 template <typename T, int VEC, bool GX, int MTW>
 __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, float* smem) {
