@@ -59,7 +59,7 @@ struct HeadArgs {
   int gx_tile_px, gx_tiles_per_sample;         // ... of k_head_gemm<GX>
   int fw_kw, gx_kw;                            // waves of a workgroup that split the K steps (1, 2, 4)
   int fw_mtw, gx_mtw;                          // M tiles per wave (template parameter of the launch the level rides in)
-  int nwg_out, out_hl_max;                     // k_head_out: workgroups (runs of kHeadOutPx pixels), LDS floats per staged channel (launch maximum)
+  int nwg_out, out_hl_max;                     // k_head_out: workgroups (runs of out_px pixels), LDS floats per WAVE (launch maximum: rows + constants)
   int nwg1, act_ppt, act_hl_max;               // k_head_bwd_act: pixel runs of the level, pixels per thread, LDS floats of the launch's longest run
   int ncb, nshare;                             // k_head_bwd_gw: channel blocks, pixel shares per block (= partial sets of dW1)
   long long* trace;                            // MGACBAM_TRACE builds only (tools/trace_head.py), else nullptr
@@ -393,29 +393,40 @@ __global__ __launch_bounds__(kBlock) void k_head_stats(const Group<HeadArgs> G) 
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_head_out: logits = conv3x3(SiLU(gamma * zhat + beta)) + bias                                  segmentation.py:83-92
-//   workgroup = a run of kHeadOutPx = 256 consecutive pixels of one sample (H*W flattened: full lanes whatever the image shape); its
-//   4 waves cover the SAME pixels (lane = 4 consecutive ones) and split the hidden channels 4 ways, so a level with many channels and
-//   few pixels (P5) still has a short chain per workgroup; the four partial sums meet in LDS.  Per pass a wave stages the activations
-//   of kHeadJO of its channels over the run plus W+1 pixels either side (zero outside the sample = the conv's zero padding in y), reads
-//   6 consecutive values per channel and window row for its 4 outputs and masks the taps that would wrap around a row end (padding
-//   in x).  3x3 weights and BatchNorm constants come from the per-channel table with scalar loads.
+//   workgroup = a run of out_px consecutive pixels of one sample (H*W flattened: full lanes whatever the image shape); its 4 waves
+//   cover the SAME pixels (lane = out_px / 64 consecutive ones) and split the hidden channels 4 ways; the four partial sums meet in LDS.
+//   The run length follows the channel count so that a wave stages ALL its channels in one pass at the same LDS budget -- 256 pixels
+//   x 4 channels per wave (hidden <= 16), 128 x 8 (<= 32), 64 x 16 (<= 64; more channels: passes of 16): with 256-pixel runs for
+//   every level the levels with many channels were 2-4 dependent passes deep and set the launch's duration.  A wave stages the
+//   activations of its channels over the run plus W+1 pixels either side (zero outside the sample = the conv's zero padding in y) in
+//   its own LDS rows (no workgroup barrier), reads ppl + 2 consecutive values per channel and window row for its ppl outputs and masks
+//   the taps that would wrap around a row end (padding in x).  3x3 weights and BatchNorm constants: from the per-channel table into
+//   the wave's LDS once per pass, read back as broadcasts.
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int kHeadOutPx = 256;
-constexpr int kHeadJO = 4;
-// row length of one staged channel: the run, W+1 pixels either side, and the slack of starting on a 16-byte boundary
-__host__ __device__ inline int head_out_row(int W) { return (kHeadOutPx + 2 * (W + 1) + 3 + 3) & ~3; }
+constexpr int kHeadOutPxMax = 256;
+constexpr int kHeadOutCst = 12;                                 // LDS floats per channel of constants: scale, shift, 9 weights (+1 pad)
+// run length / channels per wave and pass of a level, and the LDS row of one staged channel: the run, W+1 pixels either side and the
+// slack of starting on a 16-byte boundary
+__host__ __device__ inline void head_out_shape(int hid, int& out_px, int& jo) {
+  const int cw = (hid + 3) >> 2;
+  if (cw <= 4) { out_px = 256; jo = 4; } else if (cw <= 8) { out_px = 128; jo = 8; } else { out_px = 64; jo = 16; }
+}
+__host__ __device__ inline int head_out_row(int out_px, int W) { return (out_px + 2 * (W + 1) + 3 + 3) & ~3; }
 template <typename T, int VEC>
 __device__ __forceinline__ void head_out_body(const HeadArgs& A, const int wg, float* smem) {
   const HeadGeo& g = A.g;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int per = (g.HW + kHeadOutPx - 1) / kHeadOutPx;
-  const int b = wg / per, p0 = (wg - b * per) * kHeadOutPx;
+  int out_px, jo;
+  head_out_shape(g.hid, out_px, jo);
+  const int ppl = out_px >> 6;                                  // pixels per lane: 4, 2, 1
+  const int per = (g.HW + out_px - 1) / out_px;
+  const int b = wg / per, p0 = (wg - b * per) * out_px;
   const int halo = g.W + 1;
   const int lo = VEC == 4 ? ((p0 - halo) & ~3) : p0 - halo;     // first staged pixel (may be negative); VEC = 4: H*W % 4 == 0, every 16-byte group is wholly inside or outside the sample
-  const int nel = (p0 + kHeadOutPx + halo - lo + VEC - 1) / VEC; // VEC-groups staged per channel
+  const int nel = (p0 + out_px + halo - lo + VEC - 1) / VEC;    // VEC-groups staged per channel
   const int NQ = (nel + kWave - 1) / kWave;                     // ... per lane
-  const int HLs = A.out_hl_max;                                 // row stride in LDS (the launch's longest row)
-  const int pt = p0 + 4 * lane;                                 // this lane's first pixel
+  const int HLs = head_out_row(out_px, g.W);                    // row stride in LDS
+  const int pt = p0 + ppl * lane;                               // this lane's first pixel
   float ml[4], mr[4];                                           // 0 where the left / right tap would wrap around the row end
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -427,75 +438,98 @@ __device__ __forceinline__ void head_out_body(const HeadArgs& A, const int wg, f
   TRACE_HWID(A.trace, gid);
   TRACE_MARK(A.trace, gid, 0);
   const float* zb = A.c.z + static_cast<size_t>(b) * g.hid * g.HW;
-  float* s_w = smem + static_cast<size_t>(wave) * kHeadJO * HLs;  // this wave's staging area: written and read by this wave only
+  float* s_w = smem + static_cast<size_t>(wave) * A.out_hl_max;  // this wave's staging area ([jo][HLs] rows, then [jo][12] constants): written and read by this wave only
+  float* s_c = s_w + jo * HLs;
   const int cw = (g.hid + 3) >> 2;                              // channels per wave
   const int jlo = wave * cw, jhi = min(g.hid, jlo + cw);
-  const int npass = (cw + kHeadJO - 1) / kHeadJO;
+  const int npass = (cw + jo - 1) / jo;
   for (int ps = 0; ps < npass; ++ps) {
-    const int j0 = jlo + ps * kHeadJO;
-    const int jn = max(0, min(kHeadJO, jhi - j0));
-    float pc[kHeadJO][2 + 9];                                   // BatchNorm scale / shift and the 3x3 weights of the pass's channels: scalar registers
-#pragma unroll
-    for (int jj = 0; jj < kHeadJO; ++jj) {
-      const float* pr = A.c.par + static_cast<size_t>(min(j0 + jj, g.hid - 1)) * kHeadPar;
-      pc[jj][0] = uniform_load(pr); pc[jj][1] = uniform_load(pr + 1);
-#pragma unroll
-      for (int q = 0; q < 9; ++q) pc[jj][2 + q] = uniform_load(pr + 4 + q);
-    }
-    // stage: (channel, group) pairs in batches of SU loads per lane, all requested before the first is used; channel and group of a
-    // batch slot are wave-uniform (scalar registers), so the BatchNorm constants are scalar operands
-    constexpr int SU = VEC == 4 ? 8 : 16;
-    const int tot = jn * NQ;
+    const int j0 = jlo + ps * jo;
+    const int jn = max(0, min(jo, jhi - j0));
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (the previous pass's LDS reads are done before the rows are overwritten)
     __builtin_amdgcn_wave_barrier();
-    for (int base = 0; base < tot; base += SU) {
-      float zv[SU][VEC];
-      int jv[SU], qv[SU];
-      {
-        int jq = base / NQ, qq = base - jq * NQ;
+    // constants of the pass's channels: one load per lane and value, all in flight beside the activations
+    float cst[3];
 #pragma unroll
-        for (int u = 0; u < SU; ++u) { jv[u] = jq; qv[u] = qq; if (++qq == NQ) { qq = 0; ++jq; } }
-      }
+    for (int u = 0; u < 3; ++u) {
+      const int idx = lane + u * kWave, jj = idx / 11, q = idx - jj * 11;
+      cst[u] = 0.f;
+      if (jj < jn) cst[u] = A.c.par[static_cast<size_t>(j0 + jj) * kHeadPar + (q < 2 ? q : q + 2)];
+    }
+    // stage: batches of QU lane-groups x JU channels = 8 (VEC = 4) loads per lane, all requested before the first is used.  Everything
+    // that varies per lane (pixel, inside-the-sample test, LDS column) belongs to the lane-group, everything per channel is wave-uniform.
+    bool cst_stored = false;
+    auto stage = [&](auto QUc, auto JUc) {
+      constexpr int QU = decltype(QUc)::value, JU = decltype(JUc)::value;
+      for (int q0 = 0; q0 < NQ; q0 += QU) {
+        int idx[QU], pp[QU];
+        bool act[QU], ins[QU];
 #pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        const int idx = qv[u] * kWave + lane, p = lo + idx * VEC;
+        for (int qi = 0; qi < QU; ++qi) {
+          idx[qi] = (q0 + qi) * kWave + lane;
+          pp[qi] = lo + idx[qi] * VEC;
+          act[qi] = q0 + qi < NQ && idx[qi] < nel;
+          ins[qi] = pp[qi] >= 0 && pp[qi] < g.HW;              // outside the sample: the conv's zero padding (of the ACTIVATION)
+        }
+        for (int jb = 0; jb < jn; jb += JU) {
+          float zv[QU][JU][VEC];
 #pragma unroll
-        for (int r = 0; r < VEC; ++r) zv[u][r] = 0.f;
-        if (base + u < tot && idx < nel && p >= 0 && p < g.HW) load_vec<float, VEC>(zb + static_cast<size_t>(j0 + jv[u]) * g.HW + p, zv[u]);
-      }
+          for (int ji = 0; ji < JU; ++ji) {
+            const float* zr = zb + static_cast<size_t>(j0 + min(jb + ji, jn - 1)) * g.HW;   // uniform
 #pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        const int idx = qv[u] * kWave + lane, p = lo + idx * VEC;
-        if (base + u < tot && idx < nel) {
-          float sc = pc[0][0], sh = pc[0][1];                   // (jv is wave-uniform: scalar selects)
+            for (int qi = 0; qi < QU; ++qi) {
 #pragma unroll
-          for (int jj = 1; jj < kHeadJO; ++jj)
-            if (jv[u] == jj) { sc = pc[jj][0]; sh = pc[jj][1]; }
-          const bool inside = p >= 0 && p < g.HW;               // outside the sample: the conv's zero padding (of the ACTIVATION)
-          float o[VEC];
+              for (int r = 0; r < VEC; ++r) zv[qi][ji][r] = 0.f;
+              if (jb + ji < jn && act[qi] && ins[qi]) load_vec<float, VEC>(zr + pp[qi], zv[qi][ji]);
+            }
+          }
+          if (!cst_stored) {                                    // (uniform) the constants arrived with or before the first batch
 #pragma unroll
-          for (int r = 0; r < VEC; ++r) o[r] = inside ? siluf(zv[u][r] * sc + sh) : 0.f;
-          store_vec<float, VEC>(s_w + jv[u] * HLs + idx * VEC, o);
+            for (int u = 0; u < 3; ++u) {
+              const int ci = lane + u * kWave, jj = ci / 11, q = ci - jj * 11;
+              if (jj < jn) s_c[jj * kHeadOutCst + q] = cst[u];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            cst_stored = true;
+          }
+#pragma unroll
+          for (int ji = 0; ji < JU; ++ji) {
+            if (jb + ji < jn) {                                 // uniform
+              const float sc = s_c[(jb + ji) * kHeadOutCst], sh = s_c[(jb + ji) * kHeadOutCst + 1];   // uniform address: LDS broadcast
+#pragma unroll
+              for (int qi = 0; qi < QU; ++qi) {
+                if (act[qi]) {
+                  float o[VEC];
+#pragma unroll
+                  for (int r = 0; r < VEC; ++r) o[r] = ins[qi] ? siluf(zv[qi][ji][r] * sc + sh) : 0.f;
+                  store_vec<float, VEC>(s_w + (jb + ji) * HLs + idx[qi] * VEC, o);
+                }
+              }
+            }
+          }
         }
       }
-    }
+    };
+    if (NQ == 1) stage(std::integral_constant<int, 1>{}, std::integral_constant<int, VEC == 4 ? 8 : 16>{});
+    else stage(std::integral_constant<int, 2>{}, std::integral_constant<int, VEC == 4 ? 4 : 8>{});
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     if (ps == 0) TRACE_MARK(A.trace, gid, 1);                    // first pass staged
+    for (int jj = 0; jj < jn; ++jj) {
+      float w[9];
 #pragma unroll
-    for (int jj = 0; jj < kHeadJO; ++jj) {
-      if (jj >= jn) break;                                      // uniform
-      const float* w = pc[jj] + 2;                               // SGPR operands
+      for (int q = 0; q < 9; ++q) w[q] = s_c[jj * kHeadOutCst + 2 + q];
       const float* a = s_w + jj * HLs + (pt - lo);               // activation of pixel pt
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const float* row = a + (u - 1) * g.W - 1;
         float s6[6];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) s6[q] = row[q];
+        for (int q = 0; q < 6; ++q) s6[q] = q < ppl + 2 ? row[q] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          acc[i] += w[u * 3] * (ml[i] * s6[i]) + w[u * 3 + 1] * s6[i + 1] + w[u * 3 + 2] * (mr[i] * s6[i + 2]);
+          if (i < ppl) acc[i] += w[u * 3] * (ml[i] * s6[i]) + w[u * 3 + 1] * s6[i + 1] + w[u * 3 + 2] * (mr[i] * s6[i + 2]);
       }
     }
   }
@@ -513,7 +547,7 @@ __device__ __forceinline__ void head_out_body(const HeadArgs& A, const int wg, f
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float v = ((acc[i] + s_acc[(4 + i) * kWave + lane]) + (s_acc[(8 + i) * kWave + lane] + s_acc[(12 + i) * kWave + lane])) + bias;
-      if (pt + i < g.HW) lo_[pt + i] = from_f32<T>(v);
+      if (i < ppl && pt + i < p0 + out_px && pt + i < g.HW) lo_[pt + i] = from_f32<T>(v);
     }
   }
 #ifdef MGACBAM_TRACE
@@ -523,7 +557,7 @@ __device__ __forceinline__ void head_out_body(const HeadArgs& A, const int wg, f
 }
 
 template <typename T, int VEC>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void k_head_out(const Group<HeadArgs> G) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_head_out(const Group<HeadArgs> G) {
   extern __shared__ __align__(16) float smem[];
   int local;
   const int l = find_level(G, blockIdx.x, local);

@@ -1092,7 +1092,7 @@ static HeadTiling head_tiling(int B, int C, int H, int W, int hidden) {
   head_waves(t.cp / 16, t.gx_mtw, hidden, pw, t.gx_kw);
   t.gx_tile_px = pw * 16 * t.vec;
   t.gx_tps = (HW + t.gx_tile_px - 1) / t.gx_tile_px;
-  t.nwg_out = B * ((HW + kHeadOutPx - 1) / kHeadOutPx);
+  { int opx, ojo; head_out_shape(hidden, opx, ojo); t.nwg_out = B * ((HW + opx - 1) / opx); }
   t.act_ppt = HW >= 2048 ? 4 : (HW >= 512 ? 2 : 1);             // pixels per thread of k_head_bwd_act (amortises its per-channel reductions)
   t.nwg1 = B * ((HW + kBlock * t.act_ppt - 1) / (kBlock * t.act_ppt));
   t.act_hl = kBlock * t.act_ppt + 2 * (W + 1);
@@ -1214,11 +1214,15 @@ static int head_forward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t s
     if (int e = launch_status("k_head_stats")) return e;
   }
   {
-    int ohl = 0;
-    for (int l = 0; l < n; ++l) ohl = std::max(ohl, head_out_row(lv[l].g.W));
+    int ohl = 0;                                                  // LDS floats per wave: the level's rows and constants
+    for (int l = 0; l < n; ++l) {
+      int opx, ojo;
+      head_out_shape(lv[l].g.hid, opx, ojo);
+      ohl = std::max(ohl, ojo * (head_out_row(opx, lv[l].g.W) + kHeadOutCst));
+    }
     for (int l = 0; l < n; ++l) { lv[l].out_hl_max = ohl; G.lv[l].out_hl_max = ohl; }
     const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.nwg_out; });
-    const size_t smem = std::max(static_cast<size_t>(4) * kHeadJO * ohl, static_cast<size_t>(16) * kWave) * sizeof(float);
+    const size_t smem = std::max(static_cast<size_t>(4) * ohl, static_cast<size_t>(16) * kWave) * sizeof(float);
 #define CALL_HO(Tt) { if (sig.vec == 4) { LAUNCH((k_head_out<Tt, 4>), grid, smem, st, G); } else { LAUNCH((k_head_out<Tt, 1>), grid, smem, st, G); } }
     switch (sig.dtype) {
       case MGACBAM_F32: CALL_HO(float); break;
