@@ -10,7 +10,7 @@
 //                                                        dW_h (9 taps), db_h
 //                        k_head_bwd_fin partials     -> dgamma, dbeta, dW_h, db_h and the per-channel constants of g_z
 //                        k_head_gemm<X> g_a, z       -> g_z on the fly -> gx (+)= W1^T g_z  (1 write, 1 read when accumulating)  [MFMA]
-//                        k_head_bwd_gw  g_a, z, x    -> partials of dW1 = sum_px g_z x^T  (x: 1 read)                            [MFMA]
+//                        k_head_bwd_gw2 g_a, z, x    -> partials of dW1 = sum_px g_z x^T  (x: 1 read; operands through LDS; _gw: direct) [MFMA]
 //                        k_head_bwd_gwf partials     -> dW1
 // One launch covers every level of the call (P3+P4+P5), as everywhere in this library.
 // The 1x1 conv is the only GEMM-shaped piece next to the hot path: M = hid (16..256), K = C (64..768), N = B*H*W.  fp32 MFMA runs at the
@@ -61,7 +61,7 @@ struct HeadArgs {
   int fw_mtw, gx_mtw;                          // M tiles per wave (template parameter of the launch the level rides in)
   int nwg_out, out_hl_max;                     // k_head_out: workgroups (runs of out_px pixels), LDS floats per WAVE (launch maximum: rows + constants)
   int nwg1, act_ppt, act_hl_max;               // k_head_bwd_act: pixel runs of the level, pixels per thread, LDS floats of the launch's longest run
-  int ncb, nshare;                             // k_head_bwd_gw: channel blocks, pixel shares per block (= partial sets of dW1)
+  int ncb, nshare, gw2;                        // k_head_bwd_gw[2]: channel blocks, pixel shares per block (= partial sets of dW1), LDS-staged form
   long long* trace;                            // MGACBAM_TRACE builds only (tools/trace_head.py), else nullptr
   int trace_base;                              // first trace slot of the launch the level rides in
   int accum_gx;                                // MGAHEAD_BWD_ACCUM_GX: gx += W1^T g_z
@@ -893,9 +893,136 @@ __global__ __launch_bounds__(kBlock) void k_head_bwd_gw(const Group<HeadArgs> G)
   head_bwd_gw_body<T, VEC>(G.lv[l], local, smem);
 }
 
-// k_head_bwd_gwf: dW1[j,c] = sum over the pixel shares: workgroup = 32 outputs x 8 share strides, up to 16 loads in flight per thread
-//   (256 shares = two round trips), then a fixed-order combine through LDS
-constexpr int kHeadGwfOut = 32;
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_head_bwd_gw2: the same product with both operands staged through LDS (H*W % 4 == 0, hid <= 64; k_head_bwd_gw otherwise).
+//   Why: in the MFMA operand layout only 4 lanes share a channel row, so k_head_bwd_gw's global loads touch 64 B per row and
+//   instruction -- 3.1 TB/s whatever the occupancy, share count or prefetch depth (notes there).  Here the global loads are
+//   row-contiguous (a wave-load = 4 rows x 256 B, like the forward GEMM's 5+ TB/s), LDS does the transposition into operands:
+//   workgroup = (channel block of 64 channels, pixel share); per chunk of 64 consecutive pixels of one sample
+//     registers -> LDS:  x tile [64 channels][64 px], g_z tile [hidp][64 px] (g_z formed from g_a, z while storing); row pitch 68 floats:
+//                        16-byte aligned, and the 16 lanes of a quarter wave (16 rows, same 16-byte column) hit 16 x 4 distinct banks
+//     next chunk's global loads are issued, then the MFMAs of this chunk run from LDS (ds_read_b128: 4 K steps per read);
+//   wave w owns channel tile w and every hidden tile (MT x 16 accumulator registers): no cross-wave sum at the end.
+//   Two barriers per chunk; the loads of chunk i+1 are in flight during the MFMAs of chunk i.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kHeadGwPx = 64;                                   // pixels per chunk
+constexpr int kHeadGwPitch = kHeadGwPx + 4;                     // LDS row pitch (floats)
+template <typename T>
+__device__ __forceinline__ void head_bwd_gw2_body(const HeadArgs& A, const int wg, float* smem) {
+  const HeadGeo& g = A.g;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int cb = wg / A.nshare, share = wg - cb * A.nshare;
+  const int c0 = cb * kHeadCB;
+  const int MT = g.hidp >> 4;                                   // <= 4 (host)
+  const int nch = (g.HW + kHeadGwPx - 1) / kHeadGwPx;           // chunks per sample
+  const int total = g.B * nch;
+  float* s_kst = smem;                                          // [5][hidp]
+  float* s_x = smem + 5 * g.hidp;                               // [64][pitch]
+  float* s_g = s_x + kHeadCB * kHeadGwPitch;                    // [hidp][pitch]
+  const int gid = 40960 + blockIdx.x;
+  TRACE_HWID(A.trace, gid);
+  TRACE_MARK(A.trace, gid, 0);
+  for (int i = tid; i < 5 * g.hidp; i += kBlock) s_kst[i] = A.s.kst[i];
+  // staging roles: a wave-load covers 4 rows x 256 B (lane: row lq of the group, 16-byte column lr)
+  //   x: wave w stages channel rows 16w .. 16w+15 (4 loads); g_z: hidden rows in groups of 4, dealt round-robin over the waves
+  const int ngz = g.hidp >> 2;                                  // row groups of g_z (4 per hidden tile)
+  constexpr int GZ = 4;                                         // row groups per wave at most (hidp <= 64)
+  float xv[4][4], gav[GZ][4], zvv[GZ][4];
+  auto issue = [&](const int ch) {
+    const int b = ch / nch, px0 = (ch - b * nch) * kHeadGwPx + 4 * lr;
+    const bool pok = ch < total && px0 < g.HW;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + wave * 16 + q * 4 + lq;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xv[q][r] = 0.f;
+      if (pok && c < g.C) load_vec<T, 4>(static_cast<const T*>(A.x) + (static_cast<size_t>(b) * g.C + c) * g.HW + px0, xv[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < GZ; ++q) {
+      const int j = (wave + 4 * q) * 4 + lq;                    // row group wave + 4q
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { gav[q][r] = 0.f; zvv[q][r] = 0.f; }
+      if (wave + 4 * q < ngz && pok && j < g.hid) {
+        const size_t o = (static_cast<size_t>(b) * g.hid + j) * g.HW + px0;
+        load_vec<float, 4>(A.s.ga + o, gav[q]);
+        load_vec<float, 4>(A.c.z + o, zvv[q]);
+      }
+    }
+  };
+  auto to_lds = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) store_vec<float, 4>(s_x + (wave * 16 + q * 4 + lq) * kHeadGwPitch + 4 * lr, xv[q]);
+#pragma unroll
+    for (int q = 0; q < GZ; ++q) {
+      if (wave + 4 * q < ngz) {                                 // uniform
+        const int j = (wave + 4 * q) * 4 + lq;
+        const float kj = s_kst[j], mean = s_kst[g.hidp + j], rstd = s_kst[2 * g.hidp + j], gbn = s_kst[3 * g.hidp + j], ggn = s_kst[4 * g.hidp + j];
+        float gz[4];                                            // (pixels that were not loaded meet x = 0; padding rows have zero constants)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gz[r] = kj * (gav[q][r] - gbn - (zvv[q][r] - mean) * rstd * ggn);
+        store_vec<float, 4>(s_g + j * kHeadGwPitch + 4 * lr, gz);
+      }
+    }
+  };
+  v4f32 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = v4f32{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();                                              // s_kst
+  TRACE_MARK(A.trace, gid, 1);                                  // constants staged
+  int ch = share;
+  issue(ch);
+  for (; ch < total; ch += A.nshare) {                          // (uniform over the workgroup)
+    __syncthreads();                                            // everyone is done reading the previous chunk
+    to_lds();
+    __syncthreads();
+    issue(ch + A.nshare);                                       // in flight during the MFMAs below (a chunk past the end loads nothing)
+#pragma unroll
+    for (int sp = 0; sp < kHeadGwPx / 16; ++sp) {               // 16 pixels = 4 K steps per LDS read
+      float bq[4];
+      load_vec<float, 4>(s_x + (wave * 16 + lr) * kHeadGwPitch + sp * 16 + 4 * lq, bq);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < MT) {                                           // uniform
+          float aq[4];
+          load_vec<float, 4>(s_g + (t * 16 + lr) * kHeadGwPitch + sp * 16 + 4 * lq, aq);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[r], bq[r], acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+#ifdef MGACBAM_TRACE
+  if (acc[0][0] == 1.2345e30f) s_x[0] = 0.f;
+  TRACE_MARK(A.trace, gid, 2);                                  // wave 0: pixel loop done
+#endif
+  // D layout: lane l, register v: row (hidden) 4*(l/16)+v, column (channel) l%16; wave w owns channel tile w
+  float* outp = A.s.gwpart + static_cast<size_t>(wg) * g.hidp * kHeadCB;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t < MT) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) outp[static_cast<size_t>(t * 16 + lq * 4 + v) * kHeadCB + wave * 16 + lr] = acc[t][v];
+    }
+  }
+#ifdef MGACBAM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TRACE_MARK(A.trace, gid, 10);
+#endif
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void k_head_bwd_gw2(const Group<HeadArgs> G) {
+  extern __shared__ __align__(16) float smem[];
+  int local;
+  const int l = find_level(G, blockIdx.x, local);
+  head_bwd_gw2_body<T>(G.lv[l], local, smem);
+}
+
+// k_head_bwd_gwf: dW1[j,c] = sum over the pixel shares: workgroup = 16 outputs x 16 share strides, up to 16 loads in flight per thread
+//   (512 shares = two round trips), then a fixed-order combine through LDS
+constexpr int kHeadGwfOut = 16;
 __global__ __launch_bounds__(kBlock) void k_head_bwd_gwf(const Group<HeadArgs> G) {
   __shared__ float red[kBlock];
   int local;

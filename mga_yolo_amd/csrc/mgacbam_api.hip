@@ -1067,7 +1067,7 @@ static int head_check_shape(int B, int C, int H, int W, int hidden) {
     return fail(MGACBAM_E_SHAPE, "mask head: tensor too large B=%d C=%d H=%d W=%d", B, C, H, W);
   return 0;
 }
-struct HeadTiling { int vec, hidp, cp, tile_px, tps, nwg, gx_tile_px, gx_tps, fw_kw, gx_kw, fw_mtw, gx_mtw, nwg_out, nwg1, act_ppt, act_hl, ncb, nshare; };
+struct HeadTiling { int vec, hidp, cp, tile_px, tps, nwg, gx_tile_px, gx_tps, fw_kw, gx_kw, fw_mtw, gx_mtw, nwg_out, nwg1, act_ppt, act_hl, ncb, nshare, gw2; };
 // wave arrangement of k_head_gemm (head.cuh): MW waves along M for `mtiles` 16-output tiles, KW waves along K when K is long (a chain of
 // K/4 dependent steps otherwise), the rest along pixels
 static void head_waves(int mtiles, int mtw, int K, int& pw, int& kw) {
@@ -1103,6 +1103,12 @@ static HeadTiling head_tiling(int B, int C, int H, int W, int hidden) {
   const long long chunks = static_cast<long long>(B) * ((HW + 4 * t.vec - 1) / (4 * t.vec));
   ns = std::min(ns, (chunks + 7) / 8);
   t.nshare = static_cast<int>(std::max(32ll, std::min(256ll, ns)));
+  t.gw2 = (t.vec == 4 && t.hidp <= 64) ? 1 : 0;                     // k_head_bwd_gw2 (operands through LDS): a share = every nshare-th 64-pixel chunk
+  if (t.gw2) {
+    const long long chunks64 = static_cast<long long>(B) * ((HW + kHeadGwPx - 1) / kHeadGwPx);
+    const long long cap = std::max(1ll, std::min(512ll, (4ll << 20) / per_share));
+    t.nshare = static_cast<int>(std::max(1ll, std::min(cap, chunks64 / 4)));   // (measured: 2-4 chunks per workgroup and 512-2048 shares all within 1 %; 6+ chunks, one resident round: +12 %)
+  }
   return t;
 }
 struct HeadCtxLayout { size_t z, mean, rstd, par, part, total; };
@@ -1157,7 +1163,7 @@ static int head_common(const mgahead_params_t& P, int B, int C, int H, int W, in
   A.tile_px = t.tile_px; A.tiles_per_sample = t.tps; A.nwg = t.nwg;
   A.gx_tile_px = t.gx_tile_px; A.gx_tiles_per_sample = t.gx_tps; A.fw_kw = t.fw_kw; A.gx_kw = t.gx_kw; A.fw_mtw = t.fw_mtw; A.gx_mtw = t.gx_mtw;
   A.trace = knobs().trace; A.trace_base = 0;
-  A.nwg_out = t.nwg_out; A.nwg1 = t.nwg1; A.act_ppt = t.act_ppt; A.act_hl_max = t.act_hl; A.ncb = t.ncb; A.nshare = t.nshare;
+  A.nwg_out = t.nwg_out; A.nwg1 = t.nwg1; A.act_ppt = t.act_ppt; A.act_hl_max = t.act_hl; A.ncb = t.ncb; A.nshare = t.nshare; A.gw2 = t.gw2;
   sig = Sig{dtype, t.vec, 0, 0, 0, 0};
   return 0;
 }
@@ -1286,15 +1292,35 @@ static int head_backward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t 
     if (int e = launch_status("k_head_gemm<gx>")) return e;
   }
   {
-    const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.ncb * a.nshare; });
-    size_t smem = 0;
-    for (int l = 0; l < n; ++l) smem = std::max(smem, (5 * static_cast<size_t>(lv[l].g.hidp) + 1024) * sizeof(float));
-#define CALL_HW(Tt, Vv) LAUNCH((k_head_bwd_gw<Tt, Vv>), grid, smem, st, G)
+    for (int pass = 0; pass < 2; ++pass) {                         // pass 0: the levels that take the LDS-staged form, pass 1: the rest
+      Group<HeadArgs> Gw;
+      Gw.n = 0;
+      int grid = 0;
+      size_t smem = 0;
+      for (int l = 0; l < n; ++l)
+        if ((lv[l].gw2 != 0) == (pass == 0)) {
+          Gw.lv[Gw.n] = G.lv[l]; Gw.start[Gw.n] = grid; grid += lv[l].ncb * lv[l].nshare; ++Gw.n;
+          const size_t hp = static_cast<size_t>(lv[l].g.hidp);
+          smem = std::max(smem, (pass == 0 ? 5 * hp + (kHeadCB + hp) * kHeadGwPitch : 5 * hp + 1024) * sizeof(float));
+        }
+      if (!Gw.n) continue;
+      Gw.start[Gw.n] = grid;
+      if (pass == 0) {
+        switch (sig.dtype) {
+          case MGACBAM_F32: LAUNCH(k_head_bwd_gw2<float>, grid, smem, st, Gw); break;
+          case MGACBAM_F16: LAUNCH(k_head_bwd_gw2<__half>, grid, smem, st, Gw); break;
+          default: LAUNCH(k_head_bwd_gw2<bf16_t>, grid, smem, st, Gw); break;
+        }
+        if (int e = launch_status("k_head_bwd_gw2")) return e;
+        continue;
+      }
+#define CALL_HW(Tt, Vv) LAUNCH((k_head_bwd_gw<Tt, Vv>), grid, smem, st, Gw)
     if (sig.dtype == MGACBAM_F32) { if (sig.vec == 4) { CALL_HW(float, 4); } else { CALL_HW(float, 1); } }
     else if (sig.dtype == MGACBAM_F16) { if (sig.vec == 4) { CALL_HW(__half, 4); } else { CALL_HW(__half, 1); } }
     else { if (sig.vec == 4) { CALL_HW(bf16_t, 4); } else { CALL_HW(bf16_t, 1); } }
 #undef CALL_HW
     if (int e = launch_status("k_head_bwd_gw")) return e;
+    }
   }
   {
     const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return (a.g.hid * a.g.C + kHeadGwfOut - 1) / kHeadGwfOut; });
