@@ -66,7 +66,6 @@ __device__ __forceinline__ float seg_target(const SegLevel& L, int b, int y, int
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_seg_partial(const SegArgs A) {
-  __shared__ float red[8];
   int l = 0;
 #pragma unroll
   for (int i = 1; i < kSegMaxLevels; ++i)
@@ -77,28 +76,54 @@ __global__ __launch_bounds__(kBlock) void k_seg_partial(const SegArgs A) {
   const int HW = L.H * L.W;
   const T* xp = static_cast<const T*>(L.logits) + static_cast<size_t>(b) * HW;
   float s_bce = 0.f, s_i = 0.f, s_p = 0.f, s_t = 0.f;
-  for (int i = part * kBlock + threadIdx.x; i < HW; i += kSegParts * kBlock) {
-    const float x = to_f32<T>(xp[i]);
-    const int y = i / L.W;
-    const float t = seg_target(L, b, y, i - y * L.W);
-    const float e = expf(-fabsf(x));
-    const float ce = fmaxf(x, 0.f) - x * t + log1pf(e);      // binary_cross_entropy_with_logits, elementwise
-    const float p = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);   // sigmoid
-    if (A.ufl) {                                             // _lmf, segmentation.py:44-52
-      const bool pos = t > 0.5f;
-      const float pt = fminf(fmaxf(pos ? p : 1.f - p, kSegEps), 1.f - kSegEps);
-      const float base = fmaxf(1.f - pt, kSegEps);
-      s_bce += powf(base, 1.f - A.u_gamma) * ce * (pos ? A.u_delta : 1.f - A.u_delta);
-    } else {
-      s_bce += ce;
+  // batches of 4 positions per thread: their logits and targets are requested together (one position per loop trip is a chain of
+  // dependent trips to memory, and this kernel is nothing but latency)
+  constexpr int U = 4;
+  for (int i0 = part * kBlock + threadIdx.x; i0 < HW; i0 += U * kSegParts * kBlock) {
+    float xv[U], tv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * kSegParts * kBlock;
+      xv[u] = 0.f; tv[u] = 0.f;
+      if (i < HW) {
+        xv[u] = to_f32<T>(xp[i]);
+        const int y = i / L.W;
+        tv[u] = seg_target(L, b, y, i - y * L.W);
+      }
     }
-    s_i += p * t; s_p += p; s_t += t;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (i0 + u * kSegParts * kBlock < HW) {
+        const float x = xv[u], t = tv[u];
+        const float e = expf(-fabsf(x));
+        const float ce = fmaxf(x, 0.f) - x * t + log1pf(e);      // binary_cross_entropy_with_logits, elementwise
+        const float p = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);   // sigmoid
+        if (A.ufl) {                                             // _lmf, segmentation.py:44-52
+          const bool pos = t > 0.5f;
+          const float pt = fminf(fmaxf(pos ? p : 1.f - p, kSegEps), 1.f - kSegEps);
+          const float base = fmaxf(1.f - pt, kSegEps);
+          s_bce += powf(base, 1.f - A.u_gamma) * ce * (pos ? A.u_delta : 1.f - A.u_delta);
+        } else {
+          s_bce += ce;
+        }
+        s_i += p * t; s_p += p; s_t += t;
+      }
+    }
   }
+  // the four sums together: wave sums (DPP), one trip through LDS, fixed order over the waves
+  __shared__ float red4[kBlock / kWave][4];
   float v[4] = {s_bce, s_i, s_p, s_t};
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float r = block_sum(v[q], threadIdx.x, red);
-    if (threadIdx.x == 0) L.part[(static_cast<size_t>(b) * kSegParts + part) * 4 + q] = r;
+  for (int q = 0; q < 4; ++q) v[q] = wave_group_sum(v[q], kWave);
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red4[threadIdx.x >> 6][q] = v[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float r = red4[0][threadIdx.x];
+    for (int w = 1; w < kBlock / kWave; ++w) r += red4[w][threadIdx.x];
+    L.part[(static_cast<size_t>(b) * kSegParts + part) * 4 + threadIdx.x] = r;
   }
 }
 
