@@ -592,6 +592,31 @@ __device__ __forceinline__ void head_bwd_act_body(const HeadArgs& A, const int w
   TRACE_MARK(A.trace, gid, 0);
   const T* gl = static_cast<const T*>(A.gl) + static_cast<size_t>(b) * g.HW;
   const float* gl2 = A.gl2 ? A.gl2 + static_cast<size_t>(b) * g.HW : nullptr;
+  // the first (normally only) channel batch's z values and constants are requested before anything else: they depend on nothing the
+  // staging below produces, and every dependent trip to memory is ~1.3 us of a 7 us workgroup
+  const float* zb = A.c.z + static_cast<size_t>(b) * g.hid * g.HW;
+  float zq[ZU][PP];
+  float pc[ZU][4 + 9];
+  auto fetch = [&](const int j0) {
+    const int jn = min(ZU, jhi - j0);
+#pragma unroll
+    for (int jj = 0; jj < ZU; ++jj)
+#pragma unroll
+      for (int i = 0; i < PP; ++i) {
+        const int p = p0 + tid + i * kBlock;
+        zq[jj][i] = 0.f;
+        if (jj < jn && i < ppt && p < g.HW) zq[jj][i] = zb[static_cast<size_t>(j0 + jj) * g.HW + p];
+      }
+    // the channels' constants (BatchNorm scale / shift / mean / rstd, 3x3 weights) into scalar registers, once: read inside the pixel
+    // loop they were vector loads re-issued after every g_a store (possible alias), 16 dependent round trips per thread
+#pragma unroll
+    for (int jj = 0; jj < ZU; ++jj) {
+      const float* pr = A.c.par + static_cast<size_t>(min(j0 + jj, g.hid - 1)) * kHeadPar;
+#pragma unroll
+      for (int q = 0; q < 13; ++q) pc[jj][q] = uniform_load(pr + q);
+    }
+  };
+  fetch(jlo);
   for (int i = tid; i < HL; i += kBlock) {
     const int p = p0 - halo + i;
     float v = 0.f;
@@ -622,18 +647,10 @@ __device__ __forceinline__ void head_bwd_act_body(const HeadArgs& A, const int w
     }
   }
   float* part = A.s.part1 + static_cast<size_t>(wg) * g.hidp * kHeadNStat;
-  const float* zb = A.c.z + static_cast<size_t>(b) * g.hid * g.HW;
   float* gab = A.s.ga + static_cast<size_t>(b) * g.hid * g.HW;
   for (int j0 = jlo; j0 < jhi; j0 += ZU) {
     const int jn = min(ZU, jhi - j0);
-    float zq[ZU][PP];
-#pragma unroll
-    for (int jj = 0; jj < ZU; ++jj)
-#pragma unroll
-      for (int i = 0; i < PP; ++i) {
-        zq[jj][i] = 0.f;
-        if (jj < jn && in[i]) zq[jj][i] = zb[static_cast<size_t>(j0 + jj) * g.HW + p0 + tid + i * kBlock];
-      }
+    if (j0 != jlo) fetch(j0);
 #ifdef MGACBAM_TRACE
     { float tsum = 0.f;
 #pragma unroll
@@ -643,15 +660,6 @@ __device__ __forceinline__ void head_bwd_act_body(const HeadArgs& A, const int w
       if (tsum == 1.2345e30f) s_g[0] = tsum; }
     TRACE_MARK(A.trace, gid, 3);                                // z arrived
 #endif
-    // the channels' constants (BatchNorm scale / shift / mean / rstd, 3x3 weights) into scalar registers, once: read inside the pixel
-    // loop they were vector loads re-issued after every g_a store (possible alias), 16 dependent round trips per thread
-    float pc[ZU][4 + 9];
-#pragma unroll
-    for (int jj = 0; jj < ZU; ++jj) {
-      const float* pr = A.c.par + static_cast<size_t>(min(j0 + jj, g.hid - 1)) * kHeadPar;
-#pragma unroll
-      for (int q = 0; q < 13; ++q) pc[jj][q] = uniform_load(pr + q);
-    }
 #pragma unroll
     for (int jj = 0; jj < ZU; ++jj) {
       if (jj < jn) {                                            // uniform
