@@ -445,14 +445,28 @@ __global__ __launch_bounds__(kBlock) void k_bwd_reduce2(const Group<BwdArgs> G) 
     // A.nrole role workgroups share the level's A.nwsa dWsa tiles (tile t -> role t % nrole, one after the other): the host sizes nrole to
     // the slots the streaming workgroups leave idle, so that the roles displace nothing and finish inside the streaming time
     const int npad = (A.nrole + 7) & ~7;                        // keeps the streaming ids' id % 8 <-> sample alignment
+    // (tools/trace_r2.py, config 2: the 800 one-tile roles live 8.6 us each and hold 800 of the 1792 slots first, so the last streaming
+    // workgroups start at 15 us and a 19 us stream ends at 24.6.  Interleaving roles and streaming workgroups in dispatch order was
+    // measured: +2 us -- the roles first is the better of the two orders; the fix is fewer slot-microseconds of role work.)
     if (local < npad) {
-      if (local < A.nrole)
+      if (local < A.nrole) {
+        TRACE_MARK(A.trace, blockIdx.x, 0);
         for (int t = local; t < A.nwsa; t += A.nrole) { bwd_wsa_body<7>(A, t, smem); __syncthreads(); }
+#ifdef MGACBAM_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TRACE_MARK(A.trace, blockIdx.x, 5);
+#endif
+      }
       return;
     }
     local -= npad;
   }
+  TRACE_MARK(A.trace, blockIdx.x, 0);
   bwd_reduce2_body<T, VEC, CPT>(A, local, smem);
+#ifdef MGACBAM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TRACE_MARK(A.trace, blockIdx.x, 10);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
