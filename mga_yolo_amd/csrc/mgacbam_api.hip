@@ -1291,7 +1291,7 @@ static int head_backward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t 
 #undef CALL_HX
     if (int e = launch_status("k_head_gemm<gx>")) return e;
   }
-  {
+  {                                                               // dW1 partials
     for (int pass = 0; pass < 2; ++pass) {                         // pass 0: the levels that take the LDS-staged form, pass 1: the rest
       Group<HeadArgs> Gw;
       Gw.n = 0;
@@ -1315,11 +1315,11 @@ static int head_backward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t 
         continue;
       }
 #define CALL_HW(Tt, Vv) LAUNCH((k_head_bwd_gw<Tt, Vv>), grid, smem, st, Gw)
-    if (sig.dtype == MGACBAM_F32) { if (sig.vec == 4) { CALL_HW(float, 4); } else { CALL_HW(float, 1); } }
-    else if (sig.dtype == MGACBAM_F16) { if (sig.vec == 4) { CALL_HW(__half, 4); } else { CALL_HW(__half, 1); } }
-    else { if (sig.vec == 4) { CALL_HW(bf16_t, 4); } else { CALL_HW(bf16_t, 1); } }
+      if (sig.dtype == MGACBAM_F32) { if (sig.vec == 4) { CALL_HW(float, 4); } else { CALL_HW(float, 1); } }
+      else if (sig.dtype == MGACBAM_F16) { if (sig.vec == 4) { CALL_HW(__half, 4); } else { CALL_HW(__half, 1); } }
+      else { if (sig.vec == 4) { CALL_HW(bf16_t, 4); } else { CALL_HW(bf16_t, 1); } }
 #undef CALL_HW
-    if (int e = launch_status("k_head_bwd_gw")) return e;
+      if (int e = launch_status("k_head_bwd_gw")) return e;
     }
   }
   {
