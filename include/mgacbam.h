@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MGACBAM_ABI_VERSION 13
+#define MGACBAM_ABI_VERSION 14
 #define MGACBAM_MAX_LEVELS 8          /* P3/P4/P5 need 3 */
 
 enum { MGACBAM_F32 = 0, MGACBAM_F16 = 1, MGACBAM_BF16 = 2 };
@@ -49,7 +49,12 @@ enum {
   MGACBAM_E_SHAPE = -2,       /* B,C,H,W,hidden,k out of range */
   MGACBAM_E_DTYPE = -3,
   MGACBAM_E_ALIGN = -4,       /* ctx/scratch not 16-byte aligned */
-  MGACBAM_E_LEVELS = -5       /* n_levels outside 1..MGACBAM_MAX_LEVELS */
+  MGACBAM_E_LEVELS = -5,      /* n_levels outside 1..MGACBAM_MAX_LEVELS */
+  MGACBAM_E_SIZE = -6         /* a caller-owned work buffer (ctx / scratch / ws) is smaller than the matching *_bytes() query answers for
+                                 this shape under the library's CURRENT knobs; last_error names the buffer, want and got.  Nothing is
+                                 launched.  (ABI 14: every work buffer travels with its capacity -- a binding that caches a size across
+                                 mgacbam_reload_env(), or passes a buffer sized for another shape, gets this code instead of
+                                 out-of-bounds device writes) */
 };
 
 /* Constructor arguments + learnable state of one block (reference masked_cbam.py:34-64).
@@ -78,6 +83,7 @@ typedef struct mgacbam_fwd_level {
   const float* mask;         /* (B,1,H,W) fp32 logits, or NULL = vanilla CBAM  */
   void* y;                   /* (B,C,H,W) output, same dtype as x              */
   void* ctx;                 /* mgacbam_ctx_bytes(): statistics saved for backward (or inspection) */
+  size_t ctx_bytes;          /* capacity of the buffer at ctx, as the caller allocated it (checked: MGACBAM_E_SIZE) */
   mgacbam_params_t p;
   int32_t B, C, H, W;
   int32_t dtype;
@@ -91,6 +97,8 @@ typedef struct mgacbam_bwd_level {
   const void* gy;            /* (B,C,H,W) dL/dy                                 */
   const void* ctx;           /* written by the matching forward                 */
   void* scratch;             /* mgacbam_bwd_scratch_bytes(), contents undefined */
+  size_t ctx_bytes;          /* capacities of the buffers at ctx / scratch as allocated (checked: MGACBAM_E_SIZE) */
+  size_t scratch_bytes;
   void* gx;                  /* (B,C,H,W) dL/dx                                 */
   float* gmask;              /* (B,1,H,W) dL/dmask, or NULL if not wanted       */
   float* gw1;                /* parameter gradients, same shapes as parameters; OVERWRITTEN (not accumulated) */
@@ -220,6 +228,7 @@ typedef struct mgacbam_eca_fwd_level {
   const float* mask;         /* (B,1,H,W) fp32 or NULL */
   void* y;
   void* ctx;                 /* mgacbam_eca_ctx_bytes() */
+  size_t ctx_bytes;          /* capacity of ctx (checked: MGACBAM_E_SIZE) */
   mgacbam_eca_params_t p;
   int32_t B, C, H, W;
   int32_t dtype;
@@ -231,6 +240,8 @@ typedef struct mgacbam_eca_bwd_level {
   const void* gy;
   const void* ctx;
   void* scratch;             /* mgacbam_eca_scratch_bytes() */
+  size_t ctx_bytes;          /* capacities of ctx / scratch (checked: MGACBAM_E_SIZE) */
+  size_t scratch_bytes;
   void* gx;
   float* gmask;              /* or NULL */
   float* gw;                 /* (1,1,k), overwritten */
@@ -270,10 +281,12 @@ typedef struct mgaseg_cfg {                                   /* SegLossConfig, 
 } mgaseg_cfg_t;
 
 size_t mgaseg_ws_bytes(const mgaseg_level_t* levels, int n_levels);   /* workspace: kept from forward to backward */
-/* out (device, 1 + 3*n floats): [0] total, then per level {bce | l_mf, dice | l_mft, combined} (the reference's log entries) */
-int mgaseg_forward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, void* ws, float* out, void* stream);
+/* ws_bytes: capacity of ws as allocated (checked against mgaseg_ws_bytes(): MGACBAM_E_SIZE)
+ * out (device, 1 + 3*n floats): [0] total, then per level {bce | l_mf, dice | l_mft, combined} (the reference's log entries) */
+int mgaseg_forward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, void* ws, size_t ws_bytes, float* out, void* stream);
 /* gout: device scalar dL/d(total) */
-int mgaseg_backward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, const void* ws, const float* gout, void* stream);
+int mgaseg_backward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, const void* ws, size_t ws_bytes, const float* gout,
+                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MGAMaskHead: the producer of the mask logits, mga_yolo/nn/modules/segmentation.py:56-110 in its default configuration
@@ -300,6 +313,7 @@ typedef struct mgahead_fwd_level {
   const void* x;               /* (B,C,H,W) feature of `dtype`                                 */
   void* logits;                /* (B,1,H,W) mask logits of `dtype`                             */
   void* ctx;                   /* mgahead_ctx_bytes(): z, batch statistics (kept for backward) */
+  size_t ctx_bytes;            /* capacity of ctx (checked: MGACBAM_E_SIZE)                    */
   mgahead_params_t p;
   int32_t B, C, H, W;
   int32_t dtype;
@@ -312,6 +326,8 @@ typedef struct mgahead_bwd_level {
                                   MaskCBAM (model.py:57-64, 196-202); passing MaskCBAM's dL/dmask here saves the add launch */
   const void* ctx;             /* written by the matching forward                              */
   void* scratch;               /* mgahead_bwd_scratch_bytes(), contents undefined              */
+  size_t ctx_bytes;            /* capacities of ctx / scratch (checked: MGACBAM_E_SIZE)        */
+  size_t scratch_bytes;
   void* gx;                    /* (B,C,H,W) dL/dx of `dtype`                                   */
   float* gw1;                  /* parameter gradients, shapes of the parameters, OVERWRITTEN   */
   float* gbn_weight;
@@ -329,7 +345,7 @@ enum { MGAHEAD_BWD_ACCUM_GX = 1 };
 
 size_t mgahead_ctx_bytes(int B, int C, int H, int W, int hidden);
 size_t mgahead_bwd_scratch_bytes(int B, int C, int H, int W, int hidden);
-int mgahead_forward(const mgahead_fwd_level_t* levels, int n_levels, void* stream);     /* 4 launches for all levels (the 1x1-conv GEMM in two: one-tile levels, the rest) */
+int mgahead_forward(const mgahead_fwd_level_t* levels, int n_levels, void* stream);     /* 3 launches for all levels at hidden <= 128 (GEMM, statistics, output); 4 when levels with hidden > 128 are present (their GEMM is a launch of its own) */
 int mgahead_backward(const mgahead_bwd_level_t* levels, int n_levels, void* stream);    /* 5 launches for all levels */
 
 /* Kendall multi-task combine of MGAModel.loss (mga_yolo/model/model.py:204-206), on the device so that no loss value has to visit
@@ -345,9 +361,9 @@ int mgakendall_backward(const float* det, int n_det, const float* seg, const flo
  * launches fewer per step; every one of these kernels is launch-latency-bound).  `out` = mgaseg_forward's out (1 + 3 * n_levels floats;
  * out[0] = the seg total the combine reads).  Backward: levels[l].glogits <- d total.sum-weighted / d logits_l, g_det[n_det],
  * g_log_vars[2]; g_seg (dL/d seg total) may be NULL. */
-int mgaseg_kendall_forward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, void* ws, float* out,
+int mgaseg_kendall_forward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, void* ws, size_t ws_bytes, float* out,
                            const float* det, int n_det, const float* log_vars, float* total, void* stream);
-int mgaseg_kendall_backward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, const void* ws, const float* out,
+int mgaseg_kendall_backward(const mgaseg_level_t* levels, int n_levels, const mgaseg_cfg_t* cfg, const void* ws, size_t ws_bytes, const float* out,
                             const float* det, int n_det, const float* log_vars, const float* g_total,
                             float* g_det, float* g_seg, float* g_log_vars, void* stream);
 

@@ -8,9 +8,10 @@ import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGACBAM_LIB") or os.path.join(_PKG, "libmgacbam.so")   # MGACBAM_LIB: A/B builds in tuning sweeps
-ABI_VERSION = 13
+ABI_VERSION = 14
 MAX_LEVELS = 8
 F32, F16, BF16 = 0, 1, 2
+E_NULL, E_SHAPE, E_DTYPE, E_ALIGN, E_LEVELS, E_SIZE = -1, -2, -3, -4, -5, -6
 # stage bit masks (include/mgacbam.h)
 FWD_STAGES = dict(pool=1, chan=2, apply=4)
 BWD_STAGES = dict(reduce1=1, convT=2, reduce2=4, wsa=8, params=16, apply=32)
@@ -31,14 +32,14 @@ class Params(C.Structure):                       # mgacbam_params_t
 
 
 class FwdLevel(C.Structure):                     # mgacbam_fwd_level_t
-    _fields_ = [("x", C.c_void_p), ("mask", C.c_void_p), ("y", C.c_void_p), ("ctx", C.c_void_p),
+    _fields_ = [("x", C.c_void_p), ("mask", C.c_void_p), ("y", C.c_void_p), ("ctx", C.c_void_p), ("ctx_bytes", C.c_size_t),
                 ("p", Params), ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("dtype", C.c_int32), ("flags", C.c_int32)]
 
 
 class BwdLevel(C.Structure):                     # mgacbam_bwd_level_t
     _fields_ = [("x", C.c_void_p), ("mask", C.c_void_p), ("gy", C.c_void_p), ("ctx", C.c_void_p),
-                ("scratch", C.c_void_p), ("gx", C.c_void_p), ("gmask", C.c_void_p),
+                ("scratch", C.c_void_p), ("ctx_bytes", C.c_size_t), ("scratch_bytes", C.c_size_t), ("gx", C.c_void_p), ("gmask", C.c_void_p),
                 ("gw1", C.c_void_p), ("gb1", C.c_void_p), ("gw2", C.c_void_p), ("gb2", C.c_void_p),
                 ("gwsa", C.c_void_p), ("gbeta", C.c_void_p),
                 ("p", Params), ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
@@ -51,12 +52,13 @@ class EcaParams(C.Structure):                    # mgacbam_eca_params_t
 
 
 class EcaFwdLevel(C.Structure):                  # mgacbam_eca_fwd_level_t
-    _fields_ = [("x", C.c_void_p), ("mask", C.c_void_p), ("y", C.c_void_p), ("ctx", C.c_void_p), ("p", EcaParams),
+    _fields_ = [("x", C.c_void_p), ("mask", C.c_void_p), ("y", C.c_void_p), ("ctx", C.c_void_p), ("ctx_bytes", C.c_size_t), ("p", EcaParams),
                 ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dtype", C.c_int32)]
 
 
 class EcaBwdLevel(C.Structure):                  # mgacbam_eca_bwd_level_t
     _fields_ = [("x", C.c_void_p), ("mask", C.c_void_p), ("gy", C.c_void_p), ("ctx", C.c_void_p), ("scratch", C.c_void_p),
+                ("ctx_bytes", C.c_size_t), ("scratch_bytes", C.c_size_t),
                 ("gx", C.c_void_p), ("gmask", C.c_void_p), ("gw", C.c_void_p), ("gbeta", C.c_void_p), ("p", EcaParams),
                 ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dtype", C.c_int32)]
 
@@ -91,12 +93,13 @@ class HeadParams(C.Structure):                   # mgahead_params_t
 
 
 class HeadFwdLevel(C.Structure):                 # mgahead_fwd_level_t
-    _fields_ = [("x", C.c_void_p), ("logits", C.c_void_p), ("ctx", C.c_void_p), ("p", HeadParams),
+    _fields_ = [("x", C.c_void_p), ("logits", C.c_void_p), ("ctx", C.c_void_p), ("ctx_bytes", C.c_size_t), ("p", HeadParams),
                 ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dtype", C.c_int32)]
 
 
 class HeadBwdLevel(C.Structure):                 # mgahead_bwd_level_t
-    _fields_ = [("x", C.c_void_p), ("g_logits", C.c_void_p), ("g_logits2", C.c_void_p), ("ctx", C.c_void_p), ("scratch", C.c_void_p), ("gx", C.c_void_p),
+    _fields_ = [("x", C.c_void_p), ("g_logits", C.c_void_p), ("g_logits2", C.c_void_p), ("ctx", C.c_void_p), ("scratch", C.c_void_p),
+                ("ctx_bytes", C.c_size_t), ("scratch_bytes", C.c_size_t), ("gx", C.c_void_p),
                 ("gw1", C.c_void_p), ("gbn_weight", C.c_void_p), ("gbn_bias", C.c_void_p), ("gwh", C.c_void_p), ("gbh", C.c_void_p),
                 ("p", HeadParams), ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dtype", C.c_int32),
                 ("flags", C.c_int32)]
@@ -127,16 +130,16 @@ SYMBOLS = {
     "mgacbam_eca_forward": (C.c_int, [C.POINTER(EcaFwdLevel), C.c_int, C.c_void_p]),
     "mgacbam_eca_backward": (C.c_int, [C.POINTER(EcaBwdLevel), C.c_int, C.c_void_p]),
     "mgaseg_ws_bytes": (C.c_size_t, [C.POINTER(SegLevel), C.c_int]),
-    "mgaseg_forward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_void_p, C.c_void_p]),
-    "mgaseg_backward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgaseg_forward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "mgaseg_backward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "mgahead_ctx_bytes": (C.c_size_t, [C.c_int] * 5),
     "mgahead_bwd_scratch_bytes": (C.c_size_t, [C.c_int] * 5),
     "mgahead_forward": (C.c_int, [C.POINTER(HeadFwdLevel), C.c_int, C.c_void_p]),
     "mgahead_backward": (C.c_int, [C.POINTER(HeadBwdLevel), C.c_int, C.c_void_p]),
     "mgakendall_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgakendall_backward": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 7),
-    "mgaseg_kendall_forward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "mgaseg_kendall_backward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6),
+    "mgaseg_kendall_forward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgaseg_kendall_backward": (C.c_int, [C.POINTER(SegLevel), C.c_int, C.POINTER(SegCfg), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6),
     "mgapmg_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_size_t, C.POINTER(PmgCfg), C.c_void_p]),
     "mgapmg_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_size_t, C.POINTER(PmgCfg), C.c_void_p]),
 }
@@ -195,6 +198,8 @@ def check(rc: int, what: str):
     if rc != 0:
         msg = load().mgacbam_last_error().decode(errors="replace")
         kind = "argument error" if rc < 0 else "HIP error"
+        if rc == E_SIZE:
+            kind = "work buffer too small (MGACBAM_E_SIZE)"
         raise RuntimeError(f"{what}: {kind} {rc}: {msg}")
 
 

@@ -3,25 +3,49 @@
 The library is built IN-TREE with hipcc (no torch C++ extension: the ABI carries no torch types, and the
 image's hipcc (ROCm 7.2) differs from torch's bundled HIP (7.0); at run time the .so resolves
 ``libamdhip64.so.7`` to the copy torch has already loaded, so both share one HIP runtime and streams).
+
+One translation unit per kernel family (csrc/api_*.hip), compiled in parallel into build/obj/<tag>/ and linked into
+mga_yolo_amd/libmgacbam.so; a unit is recompiled only when it or a header it includes (transitively) changed.
 """
 from __future__ import annotations
 
+import hashlib
 import os
+import re
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmgacbam.so")
-SOURCES = ["mgacbam_api.hip"]
+OBJ_ROOT = os.path.join(ROOT, "build", "obj")
 ARCH = "gfx950"
+_INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
 
 
-def dependencies():
-    """Everything the library is compiled from: every file under csrc/ (all .cuh are included by mgacbam_api.hip) + the public header."""
-    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cuh", ".h"))]
-    return deps + [os.path.join(ROOT, "include", "mgacbam.h")]
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.startswith("api_") and f.endswith(".hip"))
+
+
+def _includes(path: str, seen: set) -> set:
+    """Files `path` includes with quotes, transitively (relative to the including file)."""
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    for inc in _INC.findall(open(path).read()):
+        _includes(os.path.normpath(os.path.join(os.path.dirname(path), inc)), seen)
+    return seen
+
+
+def dependencies(src: str | None = None):
+    """Everything a unit (default: the whole library) is compiled from."""
+    units = [src] if src else sources()
+    deps = set()
+    for u in units:
+        _includes(os.path.join(CSRC, u), deps)
+    return sorted(deps)
 
 
 def hipcc_path() -> str:
@@ -31,30 +55,61 @@ def hipcc_path() -> str:
     return p
 
 
-def is_stale() -> bool:
-    if not os.path.exists(LIB):
+def is_stale(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(d) > t for d in dependencies())
 
 
-def build(force: bool = False, verbose: bool = False, resource_log: str | None = None, defines=(), out: str | None = None) -> str:
-    """Compile csrc/*.hip for gfx950 into mga_yolo_amd/libmgacbam.so; returns the library path."""
-    if not force and not is_stale() and not out:
-        return LIB
-    cmd = [hipcc_path(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-shared", "-fPIC",
-           "-Wno-pass-failed", "-o", out or LIB] + list(defines) + [os.path.join(CSRC, s) for s in SOURCES]
+def build(force: bool = False, verbose: bool = False, resource_log: str | None = None, defines=(), out: str | None = None,
+          jobs: int | None = None) -> str:
+    """Compile csrc/api_*.hip for gfx950 and link mga_yolo_amd/libmgacbam.so (or `out`); returns the library path.
+    `defines`: extra -D flags (A/B builds: they get an object directory of their own)."""
+    lib = out or LIB
+    if not force and not is_stale(lib):
+        return lib
+    hipcc = hipcc_path()
+    flags = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wno-pass-failed"] + list(defines)
     if resource_log:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
+        flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
+    tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
+    objdir = os.path.join(OBJ_ROOT, tag)
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src: str):
+        obj = os.path.join(objdir, src[:-4] + ".o")
+        log = obj + ".log"
+        deps = dependencies(src)
+        if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
+            return obj, (open(log).read() if os.path.exists(log) else ""), 0
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            if os.path.exists(obj):
+                os.remove(obj)
+            return obj, r.stderr, r.returncode
+        open(log, "w").write(r.stderr)
+        return obj, r.stderr, 0
+
+    srcs = sources()
+    with ThreadPoolExecutor(max_workers=jobs or min(len(srcs), os.cpu_count() or 4)) as ex:
+        results = list(ex.map(compile_one, srcs))
     if resource_log:
         with open(resource_log, "w") as f:
-            f.write(r.stderr)
+            f.write("".join(err for _, err, _ in results))
+    bad = [(s, err) for s, (_, err, rc) in zip(srcs, results) if rc]
+    if bad:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(f"--- {s}\n{err[-4000:]}" for s, err in bad))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + [o for o, _, _ in results]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
-    return out or LIB
+        raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    return lib
 
 
 if __name__ == "__main__":

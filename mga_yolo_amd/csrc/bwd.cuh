@@ -23,7 +23,7 @@
 #pragma once
 #include "args.cuh"
 #include "common.cuh"
-#include "fwd.cuh"   // ConvTile / stage_window
+#include "tile.cuh"   // ConvTile / stage_window
 
 // tuning hooks (A/B builds): unroll 1/2/4/8 and prefetch 1/2 of k_bwd_apply all measure within noise (54.5-57.7 us)
 #ifndef MGACBAM_BAPPLY_UNROLL

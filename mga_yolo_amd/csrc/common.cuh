@@ -8,6 +8,10 @@
 
 #include "args.cuh"
 
+#ifndef MGACBAM_POOL_PF
+#define MGACBAM_POOL_PF 1   // H*W positions per lane per memory round in the sweep kernels (k_pool, k_bwd_reduce2)
+#endif
+
 namespace mgacbam {
 
 constexpr int kBlock = 256;        // every kernel uses 256-thread workgroups = 4 waves

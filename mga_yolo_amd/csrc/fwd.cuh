@@ -18,10 +18,7 @@
 #pragma once
 #include "args.cuh"
 #include "common.cuh"
-
-#ifndef MGACBAM_POOL_PF
-#define MGACBAM_POOL_PF 1   // H*W positions per lane per memory round in the sweep kernels (k_pool, k_bwd_reduce2)
-#endif
+#include "tile.cuh"
 
 namespace mgacbam {
 
@@ -369,56 +366,6 @@ __global__ __launch_bounds__(kBlock) void k_chan(const Group<FwdArgs> G) {
   int local;
   const int l = find_level(G, blockIdx.x, local);
   chan_body<T, VEC, PROJ, NOPRO>(G.lv[l], local, smem);
-}
-
-// ---------------------------------------------------------------------------------------------
-// LDS staging of image planes with zero padding.  Loads are issued U at a time per thread before any LDS store,
-// so a tile costs one or two global-load latencies, not one per element.
-//   generic form: `total` elements, element idx -> (plane p, row yy, col xx) of a PH x PW window whose top-left
-//   image coordinate is (ya, xa); load(p, off) -> element `off` of plane p of this sample (H*W floats)
-// ---------------------------------------------------------------------------------------------
-template <int U, typename LoadFn>
-__device__ __forceinline__ void stage_window(float* tile, int NP, int PH, int PW, int ya, int xa, const Geo& g, LoadFn load) {
-  const int total = NP * PH * PW;
-  // idx / d == umulhi(idx, 2^32/d + 1) for idx < 2^16; d == 1 would overflow the magic, so it gets the identity
-  const unsigned mpw = PW > 1 ? 0xFFFFFFFFu / static_cast<unsigned>(PW) + 1u : 0u;
-  const unsigned mph = PH > 1 ? 0xFFFFFFFFu / static_cast<unsigned>(PH) + 1u : 0u;
-  for (int base = 0; base < total; base += kBlock * U) {
-    float v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int idx = base + u * kBlock + threadIdx.x;
-      const unsigned r = PW > 1 ? __umulhi(static_cast<unsigned>(idx), mpw) : static_cast<unsigned>(idx);   // row over all planes
-      const int xx = idx - static_cast<int>(r) * PW;
-      const unsigned p = PH > 1 ? __umulhi(r, mph) : r;
-      const int yy = static_cast<int>(r) - static_cast<int>(p) * PH;
-      const int gy_ = ya + yy, gx_ = xa + xx;
-      v[u] = 0.f;
-      if (idx < total && gy_ >= 0 && gy_ < g.H && gx_ >= 0 && gx_ < g.W) v[u] = load(static_cast<int>(p), gy_ * g.W + gx_);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int idx = base + u * kBlock + threadIdx.x;
-      if (idx < total) tile[idx] = v[u];
-    }
-  }
-}
-
-// 2-D conv tiles used by the backward conv kernel: TH rows x TW = 4*TWQ columns of one sample
-struct ConvTile {
-  int b, y0, x0, TW, TH, PW, PH, pad, k;
-};
-__device__ __forceinline__ ConvTile conv_tile(const Geo& g, const Tune& t, int k, int bid, int th) {
-  ConvTile c;
-  c.k = k; c.pad = k / 2;
-  c.TW = t.conv_twq * 4; c.TH = th;
-  c.PW = c.TW + k - 1; c.PH = c.TH + k - 1;
-  const int tiles_x = (g.W + c.TW - 1) / c.TW, tiles_y = (g.H + c.TH - 1) / c.TH;
-  const int txi = bid % tiles_x; bid /= tiles_x;
-  const int tyi = bid % tiles_y;
-  c.b = bid / tiles_y;
-  c.y0 = tyi * c.TH; c.x0 = txi * c.TW;
-  return c;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -918,27 +865,6 @@ __global__ __launch_bounds__(kBlock) GATE_OCC void k_gate(const GateGroup GG) {
   int local;
   const int l = find_level(GG.g, bid - GG.nrole, local);
   gate_body<T, VEC, K>(GG.g.lv[l], local, smem);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_resize_nearest: dst[p, y, x] = src[p, sy(y), sx(x)],  s(d) = min(floor(d * in/out), in-1) in fp32
-//   mga_yolo/nn/losses/segmentation.py:103-110 -> F.interpolate(mode="nearest"): the integer index path
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_resize_nearest(const float* __restrict__ src, float* __restrict__ dst,
-                                                           int n_planes, int in_h, int in_w, int out_h, int out_w) {
-  const float sh = static_cast<float>(in_h) / static_cast<float>(out_h);
-  const float sw = static_cast<float>(in_w) / static_cast<float>(out_w);
-  const size_t total = static_cast<size_t>(n_planes) * out_h * out_w;
-  for (size_t o = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; o < total;
-       o += static_cast<size_t>(gridDim.x) * kBlock) {
-    const int x = static_cast<int>(o % out_w);
-    const size_t r = o / out_w;
-    const int y = static_cast<int>(r % out_h);
-    const size_t p = r / out_h;
-    const int sy = min(static_cast<int>(floorf(static_cast<float>(y) * sh)), in_h - 1);
-    const int sx = min(static_cast<int>(floorf(static_cast<float>(x) * sw)), in_w - 1);
-    dst[o] = src[(p * in_h + sy) * in_w + sx];
-  }
 }
 
 }  // namespace mgacbam

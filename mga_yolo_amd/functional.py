@@ -226,13 +226,16 @@ class _PyramidFn(torch.autograd.Function):
             pc = [_ready(p) for p in params]
             y = torch.empty_like(xc)
             # FWD_FUSE / BWD_FOLD contract: the hand-off flags at the end of ctx were zero-filled once (by the pool, at creation)
-            # (the flags count calls PER TILE, so a buffer is only reused under the tiling it was used with: same element type, same knobs)
-            key = (dev.index, stream, B, Cc, H, W, cfg.hidden, x.dtype, _lib.ENV_EPOCH)
+            # (the flags count calls PER TILE, so a buffer is only reused under the tiling it was used with.  The library derives every
+            #  tiling from the level alone -- shape, element type, conv size k, knobs; never from the other levels of the call -- and
+            #  exactly those are in the key)
+            key = (dev.index, stream, B, Cc, H, W, cfg.hidden, x.dtype, _lib.ENV_EPOCH, cfg.k)
             lease = _Lease(key, _POOL.take(key, _lib.ctx_bytes(B, Cc, H, W, cfg.hidden), _lib.ctx_layout(B, Cc, H, W, cfg.hidden)["sync"], dev))
             cbuf = lease.buf
             leases.append(lease)
             L = levels[l]
             L.x, L.mask, L.y, L.ctx = xc.data_ptr(), (None if m32 is None else m32.data_ptr()), y.data_ptr(), cbuf.data_ptr()
+            L.ctx_bytes = cbuf.numel()
             L.p = _params_struct(pc, cfg)
             L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[x.dtype]
             # opt-in (MGACBAM_PROJ=1): the backward of this call will want dL/dmask, let the forward save the W1-projection
@@ -277,6 +280,7 @@ class _PyramidFn(torch.autograd.Function):
             L = levels[l]
             L.x, L.mask, L.gy, L.ctx, L.scratch = (xc.data_ptr(), None if m32 is None else m32.data_ptr(), gy.data_ptr(),
                                                    cbuf.data_ptr(), scratch.data_ptr())
+            L.ctx_bytes, L.scratch_bytes = cbuf.numel(), scratch.numel()
             L.gx, L.gmask = gx.data_ptr(), (None if gmask is None else gmask.data_ptr())
             L.gw1, L.gb1, L.gw2, L.gb2, L.gwsa, L.gbeta = (t.data_ptr() for t in pg)
             L.p = _params_struct(pc, cfg)
@@ -327,6 +331,7 @@ def forward_with_ctx(x, mask, params, cfg: BlockConfig, save_proj: bool = True):
     lv = (_lib.FwdLevel * 1)()
     L = lv[0]
     L.x, L.mask, L.y, L.ctx = xc.data_ptr(), (None if m32 is None else m32.data_ptr()), y.data_ptr(), cbuf.data_ptr()
+    L.ctx_bytes = cbuf.numel()
     L.p = _params_struct(pc, cfg)
     L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[x.dtype]
     L.flags = _lib.FWD_SAVE_PROJ if (save_proj and mask is not None) else 0
@@ -402,6 +407,7 @@ class _EcaFn(torch.autograd.Function):
             cbuf = torch.empty(lib.mgacbam_eca_ctx_bytes(B, Cc, H, W), dtype=torch.uint8, device=dev)
             L = levels[l]
             L.x, L.mask, L.y, L.ctx = xc.data_ptr(), (None if m32 is None else m32.data_ptr()), y.data_ptr(), cbuf.data_ptr()
+            L.ctx_bytes = cbuf.numel()
             L.p = _lib.EcaParams(wc.data_ptr(), bc.data_ptr(), cfg.k, int(cfg.use_sigmoid_mask), cfg.tiny_thr, cfg.eps)
             L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[x.dtype]
             keep += [xc, m32, cbuf, wc, bc]
@@ -436,6 +442,7 @@ class _EcaFn(torch.autograd.Function):
             L = levels[l]
             L.x, L.mask, L.gy, L.ctx, L.scratch = (xc.data_ptr(), None if m32 is None else m32.data_ptr(), gy.data_ptr(),
                                                    cbuf.data_ptr(), scratch.data_ptr())
+            L.ctx_bytes, L.scratch_bytes = cbuf.numel(), scratch.numel()
             L.gx, L.gmask, L.gw, L.gbeta = gx.data_ptr(), (None if gmask is None else gmask.data_ptr()), gw.data_ptr(), gb.data_ptr()
             L.p = _lib.EcaParams(wc.data_ptr(), bc.data_ptr(), cfg.k, int(cfg.use_sigmoid_mask), cfg.tiny_thr, cfg.eps)
             L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[xc.dtype]
@@ -557,7 +564,7 @@ class _HeadFn(torch.autograd.Function):
             logits = torch.empty(B, 1, H, W, dtype=x.dtype, device=dev)
             cbuf = torch.empty(lib.mgahead_ctx_bytes(B, Cc, H, W, hid), dtype=torch.uint8, device=dev)
             L = levels[l]
-            L.x, L.logits, L.ctx = xc.data_ptr(), logits.data_ptr(), cbuf.data_ptr()
+            L.x, L.logits, L.ctx, L.ctx_bytes = xc.data_ptr(), logits.data_ptr(), cbuf.data_ptr(), cbuf.numel()
             L.p = _head_params(*pc[:3], rmean, rvar, nbt, *pc[3:], hid, float(eps), float(momentum), training)
             L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[x.dtype]
             keep += [xc, cbuf, *pc, rmean, rvar]
@@ -589,6 +596,7 @@ class _HeadFn(torch.autograd.Function):
             scratch = torch.empty(lib.mgahead_bwd_scratch_bytes(B, Cc, H, W, hid), dtype=torch.uint8, device=dev)
             L = levels[l]
             L.x, L.g_logits, L.g_logits2, L.ctx, L.scratch, L.gx = xc.data_ptr(), gl.data_ptr(), None, cbuf.data_ptr(), scratch.data_ptr(), gx.data_ptr()
+            L.ctx_bytes, L.scratch_bytes = cbuf.numel(), scratch.numel()
             L.gw1, L.gbn_weight, L.gbn_bias, L.gwh, L.gbh = (t.data_ptr() for t in pg)
             L.p = _head_params(w1, gamma, beta, rmean, rvar, None, wh, bh, hid, eps, momentum, training)
             L.B, L.C, L.H, L.W, L.dtype, L.flags = B, Cc, H, W, _DTYPES[xc.dtype], 0

@@ -64,10 +64,12 @@ class PyramidPlan:
             ptr = lambda t: None if t is None else t.data_ptr()
             F, Bw = self._fwd[l], self._bwd[l]
             F.x, F.mask, F.y, F.ctx = ptr(self.x[l]), ptr(self.mask[l]), ptr(self.y[l]), ptr(self.ctx[l])
+            F.ctx_bytes = self.ctx[l].numel()
             F.p = _params_struct(ps, cfg)
             F.B, F.C, F.H, F.W, F.dtype = B, C, H, W, _DTYPES[dtype]
             F.flags = _lib.FWD_SAVE_PROJ if (with_mask and want_gmask and use_proj) else 0
             Bw.x, Bw.mask, Bw.gy, Bw.ctx, Bw.scratch = ptr(self.x[l]), ptr(self.mask[l]), ptr(self.gy[l]), ptr(self.ctx[l]), ptr(self.scratch[l])
+            Bw.ctx_bytes, Bw.scratch_bytes = self.ctx[l].numel(), self.scratch[l].numel()
             Bw.gx, Bw.gmask = ptr(self.gx[l]), ptr(self.gmask[l])
             Bw.gw1, Bw.gb1, Bw.gw2, Bw.gb2, Bw.gwsa, Bw.gbeta = (v.data_ptr() for v in views)
             Bw.p = _params_struct(ps, cfg)
@@ -202,6 +204,8 @@ class EcaPyramidPlan:
             P = _lib.EcaParams(w.data_ptr(), beta.data_ptr(), cfg.k, int(cfg.use_sigmoid_mask), cfg.tiny_thr, cfg.eps)
             F, Bw = self._fwd[l], self._bwd[l]
             F.x, F.mask, F.y, F.ctx, F.p = ptr(self.x[l]), ptr(self.mask[l]), ptr(self.y[l]), ptr(self.ctx[l]), P
+            F.ctx_bytes = Bw.ctx_bytes = self.ctx[l].numel()
+            Bw.scratch_bytes = self.scratch[l].numel()
             F.B, F.C, F.H, F.W, F.dtype = B, C, H, W, _DTYPES[dtype]
             Bw.x, Bw.mask, Bw.gy, Bw.ctx, Bw.scratch = ptr(self.x[l]), ptr(self.mask[l]), ptr(self.gy[l]), ptr(self.ctx[l]), ptr(self.scratch[l])
             Bw.gx, Bw.gmask, Bw.gw, Bw.gbeta, Bw.p = ptr(self.gx[l]), ptr(self.gmask[l]), gw.data_ptr(), gb.data_ptr(), P

@@ -61,7 +61,7 @@ class _SegFn(torch.autograd.Function):
         ws = torch.empty(lib.mgaseg_ws_bytes(levels, n), dtype=torch.uint8, device=dev)
         out = torch.empty(1 + 3 * n, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.mgaseg_forward(levels, n, C.byref(c), ws.data_ptr(), out.data_ptr(),
+            _lib.check(lib.mgaseg_forward(levels, n, C.byref(c), ws.data_ptr(), ws.numel(), out.data_ptr(),
                                           torch.cuda.current_stream(dev).cuda_stream), "mgaseg_forward")
         ctx.save_for_backward(ws, *keep)
         ctx.cfg, ctx.weights, ctx.resize = cfg, weights, resize
@@ -87,7 +87,7 @@ class _SegFn(torch.autograd.Function):
         g0 = gout[0:1].to(torch.float32).contiguous()       # only `total` is differentiable; the log entries are detached copies
         c = _lib.SegCfg(*ctx.cfg)
         with torch.cuda.device(dev):
-            _lib.check(lib.mgaseg_backward(levels, n, C.byref(c), ws.data_ptr(), g0.data_ptr(),
+            _lib.check(lib.mgaseg_backward(levels, n, C.byref(c), ws.data_ptr(), ws.numel(), g0.data_ptr(),
                                            torch.cuda.current_stream(dev).cuda_stream), "mgaseg_backward")
         return (None, None, None, *grads)
 

@@ -94,6 +94,8 @@ class SlicePlan:
             P = _head_params(w1, gamma, beta, rm, rv, nbt, wh, bh, hid, bn_eps, bn_momentum, training)
             F, Bw = self._hf[l], self._hb[l]
             F.x, F.logits, F.ctx, F.p = self.x[l].data_ptr(), self.logits[l].data_ptr(), self.head_ctx[l].data_ptr(), P
+            F.ctx_bytes = Bw.ctx_bytes = self.head_ctx[l].numel()
+            Bw.scratch_bytes = self.head_scratch[l].numel()
             F.B, F.C, F.H, F.W, F.dtype = B, Cc, H, W, _lib.F32
             gw1, gg, gb, gwh, gbh = self.head_grads[l]
             # dL/dlogits = the loss's part (seg_glogits) + MaskCBAM's dL/dmask (g_logits2): summed while the head's backward loads them
@@ -113,13 +115,13 @@ class SlicePlan:
         _lib.check(self.lib.mgahead_forward(self._hf, self.n, st), "mgahead_forward")                 # features -> mask logits
         self.cbam.forward()                                                                            # [feature, logits] -> refined
         # logits, targets -> seg_total (+ log entries) -> Kendall total, the combine riding in the loss's last launch
-        _lib.check(self.lib.mgaseg_kendall_forward(self._seg, self.n, C.byref(self._seg_cfg), self.seg_ws.data_ptr(), self.seg_out.data_ptr(),
+        _lib.check(self.lib.mgaseg_kendall_forward(self._seg, self.n, C.byref(self._seg_cfg), self.seg_ws.data_ptr(), self.seg_ws.numel(), self.seg_out.data_ptr(),
                                                    self.det_loss.data_ptr(), 3, self.log_vars.data_ptr(), self.total.data_ptr(), st),
                    "mgaseg_kendall_forward")
 
     def backward(self):
         st = self._stream()
-        _lib.check(self.lib.mgaseg_kendall_backward(self._seg, self.n, C.byref(self._seg_cfg), self.seg_ws.data_ptr(), self.seg_out.data_ptr(),
+        _lib.check(self.lib.mgaseg_kendall_backward(self._seg, self.n, C.byref(self._seg_cfg), self.seg_ws.data_ptr(), self.seg_ws.numel(), self.seg_out.data_ptr(),
                                                     self.det_loss.data_ptr(), 3, self.log_vars.data_ptr(), self.g_total.data_ptr(),
                                                     self.g_det.data_ptr(), self.g_seg.data_ptr(), self.g_log_vars.data_ptr(), st),
                    "mgaseg_kendall_backward")                                                          # -> seg_glogits, g_det, g_log_vars

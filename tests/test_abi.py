@@ -94,27 +94,170 @@ def test_argument_errors_are_reported_not_launched(built_lib):
         _lib.check(-2, "x")
 
 
-def test_struct_mirrors_have_the_header_field_order():
-    from mga_yolo_amd import _lib
+STRUCTS = {          # header struct tag -> ctypes mirror (every struct include/mgacbam.h declares)
+    "mgacbam_params": "Params", "mgacbam_fwd_level": "FwdLevel", "mgacbam_bwd_level": "BwdLevel", "mgacbam_ctx_layout": "CtxLayout",
+    "mgacbam_eca_params": "EcaParams", "mgacbam_eca_fwd_level": "EcaFwdLevel", "mgacbam_eca_bwd_level": "EcaBwdLevel",
+    "mgaseg_level": "SegLevel", "mgaseg_cfg": "SegCfg", "mgahead_params": "HeadParams", "mgahead_fwd_level": "HeadFwdLevel",
+    "mgahead_bwd_level": "HeadBwdLevel", "mgapmg_cfg": "PmgCfg",
+}
+
+
+def _header_fields(struct):
     src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    body = re.search(r"typedef struct %s \{(.*?)\}" % struct, src, re.S).group(1)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(",")
+        out.append(names[0].split()[-1].lstrip("*"))
+        out += [n.strip().lstrip("*") for n in names[1:]]
+    return out
 
-    def fields(struct):
-        body = re.search(r"typedef struct %s \{(.*?)\}" % struct, src, re.S).group(1)
-        out = []
-        for decl in body.split(";"):
-            decl = decl.strip()
-            if not decl:
-                continue
-            names = decl.split(",")
-            first = names[0].split()[-1].lstrip("*")
-            out.append(first)
-            out += [n.strip().lstrip("*") for n in names[1:]]
-        return out
 
-    assert fields("mgacbam_params") == [f[0] for f in _lib.Params._fields_]
-    assert fields("mgacbam_fwd_level") == [f[0] for f in _lib.FwdLevel._fields_]
-    assert fields("mgacbam_bwd_level") == [f[0] for f in _lib.BwdLevel._fields_]
-    assert fields("mgacbam_ctx_layout") == [f[0] for f in _lib.CtxLayout._fields_]
+def test_every_struct_of_the_header_has_a_mirror():
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    assert sorted(re.findall(r"typedef struct (\w+) \{", src)) == sorted(STRUCTS)
+
+
+@pytest.mark.parametrize("struct", sorted(STRUCTS))
+def test_struct_mirrors_have_the_header_field_order(struct):
+    from mga_yolo_amd import _lib
+    assert _header_fields(struct) == [f[0] for f in getattr(_lib, STRUCTS[struct])._fields_]
+
+
+def test_struct_mirrors_have_the_compiler_s_offsets_and_sizes(tmp_path):
+    """The C compiler's own layout of every struct (sizeof + offsetof of each field, from a program that includes the header)
+    against the ctypes mirrors: field order alone does not see a wrong width or a missed padding."""
+    import shutil
+    import subprocess
+    from mga_yolo_amd import _lib
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        pytest.skip("no C compiler")
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mgacbam.h"', "int main(void) {"]
+    for tag in sorted(STRUCTS):
+        lines.append(f'  printf("{tag} size %zu\\n", sizeof({tag}_t));')
+        for f in _header_fields(tag):
+            lines.append(f'  printf("{tag} {f} %zu\\n", offsetof({tag}_t, {f}));')
+    lines += ["  return 0;", "}"]
+    (tmp_path / "layout.c").write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    subprocess.run([cc, "-I", os.path.dirname(HEADER), str(tmp_path / "layout.c"), "-o", exe], check=True)
+    got = {}
+    for ln in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines():
+        tag, field, val = ln.split()
+        got[(tag, field)] = int(val)
+    for tag, mirror in STRUCTS.items():
+        cls = getattr(_lib, mirror)
+        assert got[(tag, "size")] == C.sizeof(cls), tag
+        for name, _ in cls._fields_:
+            assert got[(tag, name)] == getattr(cls, name).offset, (tag, name)
+
+
+def _fake(addr=0x10000):
+    return addr          # a non-NULL, 16-byte aligned "pointer": the calls below must fail before anything dereferences it
+
+
+def test_undersized_work_buffers_are_an_error_not_a_launch(built_lib):
+    """ABI 14: every work buffer travels with its capacity and every entry point checks it against the CURRENT requirement before
+    launching: MGACBAM_E_SIZE, last_error names the buffer with want / got.  (No GPU here: a call that got past the check would fail
+    differently.)"""
+    from mga_yolo_amd import _lib
+    lib = _lib.load()
+    B, Cc, H, W, hid, k = 2, 64, 16, 16, 4, 7
+    P = _lib.Params(*([_fake()] * 6), hid, k, 1, 1e-4, 1e-6)
+    need_ctx, need_scr = _lib.ctx_bytes(B, Cc, H, W, hid), _lib.scratch_bytes(B, Cc, H, W, hid, k)
+    fl = (_lib.FwdLevel * 1)()
+    F = fl[0]
+    F.x = F.mask = F.y = F.ctx = _fake()
+    F.p, F.B, F.C, F.H, F.W, F.dtype = P, B, Cc, H, W, _lib.F32
+    F.ctx_bytes = need_ctx - 16
+    assert lib.mgacbam_forward(fl, 1, None) == _lib.E_SIZE
+    msg = lib.mgacbam_last_error().decode()
+    assert "ctx" in msg and str(need_ctx) in msg and str(need_ctx - 16) in msg
+    with pytest.raises(RuntimeError, match="too small"):
+        _lib.check(_lib.E_SIZE, "x")
+    bl = (_lib.BwdLevel * 1)()
+    Bw = bl[0]
+    for f in ("x", "mask", "gy", "ctx", "scratch", "gx", "gmask", "gw1", "gb1", "gw2", "gb2", "gwsa", "gbeta"):
+        setattr(Bw, f, _fake())
+    Bw.p, Bw.B, Bw.C, Bw.H, Bw.W, Bw.dtype = P, B, Cc, H, W, _lib.F32
+    Bw.ctx_bytes, Bw.scratch_bytes = need_ctx, need_scr - 16
+    assert lib.mgacbam_backward(bl, 1, None) == _lib.E_SIZE and b"scratch" in lib.mgacbam_last_error()
+    Bw.ctx_bytes, Bw.scratch_bytes = 0, need_scr
+    assert lib.mgacbam_backward(bl, 1, None) == _lib.E_SIZE and b"ctx" in lib.mgacbam_last_error()
+    # MaskECA
+    el = (_lib.EcaFwdLevel * 1)()
+    E = el[0]
+    E.x = E.mask = E.y = E.ctx = _fake()
+    E.p = _lib.EcaParams(_fake(), _fake(), 3, 1, 1e-4, 1e-6)
+    E.B, E.C, E.H, E.W, E.dtype = B, Cc, H, W, _lib.F32
+    E.ctx_bytes = lib.mgacbam_eca_ctx_bytes(B, Cc, H, W) - 1
+    assert lib.mgacbam_eca_forward(el, 1, None) == _lib.E_SIZE
+    eb = (_lib.EcaBwdLevel * 1)()
+    Eb = eb[0]
+    for f in ("x", "mask", "gy", "ctx", "scratch", "gx", "gmask", "gw", "gbeta"):
+        setattr(Eb, f, _fake())
+    Eb.p, Eb.B, Eb.C, Eb.H, Eb.W, Eb.dtype = E.p, B, Cc, H, W, _lib.F32
+    Eb.ctx_bytes, Eb.scratch_bytes = lib.mgacbam_eca_ctx_bytes(B, Cc, H, W), lib.mgacbam_eca_scratch_bytes(B, Cc, H, W) - 1
+    assert lib.mgacbam_eca_backward(eb, 1, None) == _lib.E_SIZE and b"scratch" in lib.mgacbam_last_error()
+    # mask head
+    HP = _lib.HeadParams(*([_fake()] * 8), 16, 1e-3, 0.03, 1)
+    hf = (_lib.HeadFwdLevel * 1)()
+    Hf = hf[0]
+    Hf.x = Hf.logits = Hf.ctx = _fake()
+    Hf.p, Hf.B, Hf.C, Hf.H, Hf.W, Hf.dtype = HP, B, Cc, H, W, _lib.F32
+    Hf.ctx_bytes = lib.mgahead_ctx_bytes(B, Cc, H, W, 16) - 4
+    assert lib.mgahead_forward(hf, 1, None) == _lib.E_SIZE and b"ctx" in lib.mgacbam_last_error()
+    hb = (_lib.HeadBwdLevel * 1)()
+    Hb = hb[0]
+    for f in ("x", "g_logits", "ctx", "scratch", "gx", "gw1", "gbn_weight", "gbn_bias", "gwh", "gbh"):
+        setattr(Hb, f, _fake())
+    Hb.p, Hb.B, Hb.C, Hb.H, Hb.W, Hb.dtype = HP, B, Cc, H, W, _lib.F32
+    Hb.ctx_bytes, Hb.scratch_bytes = lib.mgahead_ctx_bytes(B, Cc, H, W, 16), lib.mgahead_bwd_scratch_bytes(B, Cc, H, W, 16) - 4
+    assert lib.mgahead_backward(hb, 1, None) == _lib.E_SIZE and b"scratch" in lib.mgacbam_last_error()
+    # segmentation loss
+    sl = (_lib.SegLevel * 1)()
+    S = sl[0]
+    S.logits = S.target = S.glogits = _fake()
+    S.B, S.H, S.W, S.Ht, S.Wt, S.dtype, S.scale_weight, S.resize = B, H, W, H, W, _lib.F32, 1.0, _lib.SEG_NEAREST
+    cfg = _lib.SegCfg(1.0, 1.0, 1.0, 1.0, 0, 0.5, 0.6, 0.5)
+    ws = lib.mgaseg_ws_bytes(sl, 1)
+    assert ws > 0
+    assert lib.mgaseg_forward(sl, 1, C.byref(cfg), _fake(), ws - 1, _fake(), None) == _lib.E_SIZE
+    assert lib.mgaseg_backward(sl, 1, C.byref(cfg), _fake(), ws - 1, _fake(), None) == _lib.E_SIZE
+    assert lib.mgaseg_kendall_forward(sl, 1, C.byref(cfg), _fake(), 0, _fake(), _fake(), 3, _fake(), _fake(), None) == _lib.E_SIZE
+    assert b"ws" in lib.mgacbam_last_error()
+
+
+def test_a_size_cached_across_a_knob_change_is_refused(built_lib, monkeypatch):
+    """Round 2's abort (gpurun_out/r2b: rc 134): the binding cached mgacbam_bwd_scratch_bytes() across mgacbam_reload_env() although
+    the launch geometry (tile counts) had changed -> undersized scratch -> out-of-bounds device writes.  The requirement is now
+    recomputed under the current knobs inside every call and the stale capacity is refused."""
+    from mga_yolo_amd import _lib
+    lib = _lib.load()
+    B, Cc, H, W, hid, k = 4, 64, 40, 40, 4, 7
+    stale = lib.mgacbam_bwd_scratch_bytes(B, Cc, H, W, hid, k)            # under the default geometry
+    monkeypatch.setenv("MGACBAM_CHAN_TX", "1")                            # one pixel vector per tile: many more tile partials
+    lib.mgacbam_reload_env()                                              # (the raw entry point: _lib.reload_env() would also drop its size cache)
+    try:
+        fresh = lib.mgacbam_bwd_scratch_bytes(B, Cc, H, W, hid, k)
+        assert fresh > stale
+        bl = (_lib.BwdLevel * 1)()
+        Bw = bl[0]
+        for f in ("x", "mask", "gy", "ctx", "scratch", "gx", "gmask", "gw1", "gb1", "gw2", "gb2", "gwsa", "gbeta"):
+            setattr(Bw, f, _fake())
+        Bw.p = _lib.Params(*([_fake()] * 6), hid, k, 1, 1e-4, 1e-6)
+        Bw.B, Bw.C, Bw.H, Bw.W, Bw.dtype = B, Cc, H, W, _lib.F32
+        Bw.ctx_bytes, Bw.scratch_bytes = _lib.ctx_bytes(B, Cc, H, W, hid), stale
+        assert lib.mgacbam_backward(bl, 1, None) == _lib.E_SIZE
+        msg = lib.mgacbam_last_error().decode()
+        assert "scratch" in msg and str(stale) in msg and str(fresh) in msg
+    finally:
+        monkeypatch.undo()
+        _lib.reload_env()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -302,20 +302,20 @@ def test_fused_loss_tail_equals_the_two_calls_bit_for_bit(built_lib, ufl):
         out = torch.zeros(1 + 3 * n, device="cuda"); total = torch.zeros(3, device="cuda")
         g_det = torch.zeros(3, device="cuda"); g_seg = torch.zeros((), device="cuda"); g_lv = torch.zeros(2, device="cuda")
         if fused:
-            _lib.check(lib.mgaseg_kendall_forward(levels, n, C.byref(cfg), ws.data_ptr(), out.data_ptr(), det.data_ptr(), 3, lv.data_ptr(),
+            _lib.check(lib.mgaseg_kendall_forward(levels, n, C.byref(cfg), ws.data_ptr(), ws.numel(), out.data_ptr(), det.data_ptr(), 3, lv.data_ptr(),
                                                   total.data_ptr(), st), "fwd")
-            _lib.check(lib.mgaseg_kendall_backward(levels, n, C.byref(cfg), ws.data_ptr(), out.data_ptr(), det.data_ptr(), 3, lv.data_ptr(),
+            _lib.check(lib.mgaseg_kendall_backward(levels, n, C.byref(cfg), ws.data_ptr(), ws.numel(), out.data_ptr(), det.data_ptr(), 3, lv.data_ptr(),
                                                    g_total.data_ptr(), g_det.data_ptr(), g_seg.data_ptr(), g_lv.data_ptr(), st), "bwd")
         else:
-            _lib.check(lib.mgaseg_forward(levels, n, C.byref(cfg), ws.data_ptr(), out.data_ptr(), st), "fwd")
+            _lib.check(lib.mgaseg_forward(levels, n, C.byref(cfg), ws.data_ptr(), ws.numel(), out.data_ptr(), st), "fwd")
             _lib.check(lib.mgakendall_forward(det.data_ptr(), 3, out.data_ptr(), lv.data_ptr(), total.data_ptr(), st), "kfwd")
             _lib.check(lib.mgakendall_backward(det.data_ptr(), 3, out.data_ptr(), lv.data_ptr(), g_total.data_ptr(), g_det.data_ptr(),
                                                g_seg.data_ptr(), g_lv.data_ptr(), st), "kbwd")
-            _lib.check(lib.mgaseg_backward(levels, n, C.byref(cfg), ws.data_ptr(), g_seg.data_ptr(), st), "bwd")
+            _lib.check(lib.mgaseg_backward(levels, n, C.byref(cfg), ws.data_ptr(), ws.numel(), g_seg.data_ptr(), st), "bwd")
         torch.cuda.synchronize()
         return [out, total, g_det, g_seg.reshape(1), g_lv] + gl
 
     for a, b in zip(run(True), run(False)):
         assert torch.equal(a, b)
     # NULL g_seg is allowed in the fused backward; a NULL total is not
-    assert lib.mgaseg_kendall_forward(None, 3, None, None, None, det.data_ptr(), 3, lv.data_ptr(), None, st) != 0
+    assert lib.mgaseg_kendall_forward(None, 3, None, None, 0, None, det.data_ptr(), 3, lv.data_ptr(), None, st) != 0

@@ -31,8 +31,8 @@ gout = torch.ones(1, device="cuda")
 
 def step():
     st = torch.cuda.current_stream().cuda_stream
-    _lib.check(lib.mgaseg_forward(lv, n, C.byref(cfg), ws.data_ptr(), out.data_ptr(), st), "fwd")
-    _lib.check(lib.mgaseg_backward(lv, n, C.byref(cfg), ws.data_ptr(), gout.data_ptr(), st), "bwd")
+    _lib.check(lib.mgaseg_forward(lv, n, C.byref(cfg), ws.data_ptr(), ws.numel(), out.data_ptr(), st), "fwd")
+    _lib.check(lib.mgaseg_backward(lv, n, C.byref(cfg), ws.data_ptr(), ws.numel(), gout.data_ptr(), st), "bwd")
 
 
 def timed(fn, steps=500, warm=50):

@@ -12,8 +12,8 @@ run ctx16 MGACBAM_CHAN_TX=16
 run ctx64 MGACBAM_CHAN_TX=64
 run order0 MGACBAM_LEVEL_ORDER=0
 run nofuse MGACBAM_FUSE_FWD=0 MGACBAM_FOLD_BWD=0
-run pf2 MGACBAM_LIB=mga_yolo_amd/variants/libmgacbam_pf2.so
-run pf4 MGACBAM_LIB=mga_yolo_amd/variants/libmgacbam_pf4.so
-run pf2cpt1 MGACBAM_LIB=mga_yolo_amd/variants/libmgacbam_pf2.so MGACBAM_POOL_CPT=1
-run pf4cpt1 MGACBAM_LIB=mga_yolo_amd/variants/libmgacbam_pf4.so MGACBAM_POOL_CPT=1
+run pf2 MGACBAM_LIB=build/variants/libmgacbam_pf2.so
+run pf4 MGACBAM_LIB=build/variants/libmgacbam_pf4.so
+run pf2cpt1 MGACBAM_LIB=build/variants/libmgacbam_pf2.so MGACBAM_POOL_CPT=1
+run pf4cpt1 MGACBAM_LIB=build/variants/libmgacbam_pf4.so MGACBAM_POOL_CPT=1
 python tools/show_bench.py $OUT/*.json

@@ -1,6 +1,6 @@
 """Poor man's thread trace of the mask-head GEMM kernels (needs a -DMGACBAM_TRACE build, see tools/trace_gate.py): thread 0 of every
 workgroup records the 100 MHz wall clock at start / K loop done / K split summed / stores issued / stores complete.
-    MGACBAM_LIB=$PWD/mga_yolo_amd/variants/libmgacbam_trace.so python tools/trace_head.py [fwd|gx] [workload]"""
+    MGACBAM_LIB=$PWD/build/variants/libmgacbam_trace.so python tools/trace_head.py [fwd|gx] [workload]"""
 import os, sys
 import numpy as np
 import torch

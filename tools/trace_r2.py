@@ -1,5 +1,5 @@
 """Per-workgroup start / end stamps of k_bwd_reduce2 (-DMGACBAM_TRACE build): sweep workgroups vs the dWsa role workgroups.
-    MGACBAM_LIB=$PWD/mga_yolo_amd/variants/libmgacbam_trace.so python tools/trace_r2.py [workload]"""
+    MGACBAM_LIB=$PWD/build/variants/libmgacbam_trace.so python tools/trace_r2.py [workload]"""
 import os, sys
 import numpy as np
 import torch
