@@ -10,6 +10,10 @@ static int head_check_shape(int B, int C, int H, int W, int hidden) {
     return fail(MGACBAM_E_SHAPE, "mask head: bad shape B=%d C=%d H=%d W=%d hidden=%d", B, C, H, W, hidden);
   if (static_cast<long long>(H) * W > (1ll << 28) || static_cast<long long>(B) * std::max(C, hidden) * H * W > (1ll << 40))
     return fail(MGACBAM_E_SHAPE, "mask head: tensor too large B=%d C=%d H=%d W=%d", B, C, H, W);
+  // the 3x3 kernels stage runs of pixels with a halo of W+1 either side in LDS: rows wider than the budget are refused here, not at launch
+  { int opx, ojo; head_out_shape(hidden, W, opx, ojo);
+    if (ojo < 1 || (static_cast<size_t>(kBlock) * 4 + 2 * (static_cast<size_t>(W) + 1) + 16 * kHeadJC * kHeadNStat) * sizeof(float) > 60 * 1024)
+      return fail(MGACBAM_E_SHAPE, "mask head: image rows of W=%d do not fit the 3x3 kernels' LDS staging (W <= ~1390)", W); }
   return 0;
 }
 struct HeadTiling { int vec, hidp, cp, tile_px, tps, nwg, gx_tile_px, gx_tps, fw_kw, gx_kw, fw_mtw, gx_mtw, nwg_out, nwg1, act_ppt, act_hl, ncb, nshare, gw2; };
@@ -37,7 +41,7 @@ static HeadTiling head_tiling(int B, int C, int H, int W, int hidden) {
   head_waves(t.cp / 16, t.gx_mtw, hidden, pw, t.gx_kw);
   t.gx_tile_px = pw * 16 * t.vec;
   t.gx_tps = (HW + t.gx_tile_px - 1) / t.gx_tile_px;
-  { int opx, ojo; head_out_shape(hidden, opx, ojo); t.nwg_out = B * ((HW + opx - 1) / opx); }
+  { int opx, ojo; head_out_shape(hidden, W, opx, ojo); t.nwg_out = B * ((HW + opx - 1) / opx); }
   t.act_ppt = HW >= 2048 ? 4 : (HW >= 512 ? 2 : 1);             // pixels per thread of k_head_bwd_act (amortises its per-channel reductions)
   t.nwg1 = B * ((HW + kBlock * t.act_ppt - 1) / (kBlock * t.act_ppt));
   t.act_hl = kBlock * t.act_ppt + 2 * (W + 1);
@@ -168,7 +172,7 @@ static int head_forward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t s
     int ohl = 0;                                                  // LDS floats per wave: the level's rows and constants
     for (int l = 0; l < n; ++l) {
       int opx, ojo;
-      head_out_shape(lv[l].g.hid, opx, ojo);
+      head_out_shape(lv[l].g.hid, lv[l].g.W, opx, ojo);
       ohl = std::max(ohl, ojo * (head_out_row(opx, lv[l].g.W) + kHeadOutCst));
     }
     for (int l = 0; l < n; ++l) { lv[l].out_hl_max = ohl; G.lv[l].out_hl_max = ohl; }

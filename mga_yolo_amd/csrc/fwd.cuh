@@ -29,6 +29,14 @@ namespace mgacbam {
 //   channels; the per-channel sums and the (max, first arg-max) pair are then reduced with wave
 //   shuffles (+ one LDS step when a row spans several waves).
 // ---------------------------------------------------------------------------------------------
+// The selector of the masked max is `sigmoid(mask) > 0.5` on fp32 values (masked_cbam.py:93,116).  With torch's sigmoid,
+// 1 / (1 + exp(-m)), that is true exactly for logits m > 1.5 * 2^-24: exp(-m) rounds to 1 - k 2^-24 with k = RN(m 2^24), 1 + that rounds
+// (ties to even) to 2 - 2^-23 or less iff k >= 2, and only then does the quotient exceed 0.5 + 2^-25, the half-way point above 0.5; at
+// m = 1.5 * 2^-24 itself exp(-m) lies just above the tie and k = 1.  Checked against torch's CPU kernel for every float near the
+// threshold and every 5th float in [2^-30, 2^-10] (vector and scalar-tail paths); pinned by tests/golden/case_boundary_logits.npz.
+// Comparing the LOGIT keeps valid / amax bit-exact where a fast sigmoid (v_exp + v_rcp, ~1e-6) could flip a pixel within ~1e-6 of 0.
+constexpr float kSelLogit = 0x1.8p-24f;
+
 template <typename T, int VEC, int CPT, bool HAS_MASK>
 __device__ __forceinline__ void pool_body(const FwdArgs& A, const int bid, float* red) {
   const Geo& g = A.g;
@@ -87,7 +95,7 @@ __device__ __forceinline__ void pool_body(const FwdArgs& A, const int bid, float
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           s[e] = g.use_sigmoid ? sigmoid_fast(m[p][e]) : m[p][e];   // masked_cbam.py:93-94
-          sel[e] = s[e] > 0.5f;                                     // masked_cbam.py:116
+          sel[e] = g.use_sigmoid ? m[p][e] > kSelLogit : s[e] > 0.5f;   // masked_cbam.py:116, decided EXACTLY (kSelLogit below)
           ssum += s[e];
         }
       } else {

@@ -131,6 +131,7 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
   const int gid = A.trace_base + blockIdx.x;
   TRACE_HWID(A.trace, gid);
   TRACE_MARK(A.trace, gid, 0);                                  // start
+  const int n_wave = GX ? 0 : max(0, min(WPX, g.HW - (tile * A.tile_px + pw * WPX)));   // real pixels of this wave's window (forward statistics)
 
   for (int mt0 = 0; mt0 < MT; mt0 += mblk) {
     const int mtn = min(mblk, MT - mt0);                        // tiles in this block
@@ -269,11 +270,11 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
         for (int v = 0; v < 4; ++v) {
           const int out = (mt0 + mt) * 16 + lk * 4 + v;
           float ov[VEC];
-          float s1 = 0.f, s2 = 0.f;
+          float s1 = 0.f;
 #pragma unroll
           for (int r = 0; r < VEC; ++r) {
             ov[r] = acc[t][r][v];
-            s1 += ov[r]; s2 += ov[r] * ov[r];                    // pixels past H*W were loaded as zeros: they add nothing
+            s1 += ov[r];                                         // pixels past H*W were loaded as zeros: they add nothing
           }
           if (out < M && px_ok) {
             if (GX) {
@@ -287,9 +288,18 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
             else store_vec<float, VEC>(A.c.z + (static_cast<size_t>(b) * g.hid + out) * g.HW + px, ov);
           }
           if (!GX && g.training) {
+            // batch statistics, Chan-style: the wave's sum and its squared deviations about ITS OWN mean (the values are still in
+            // registers, so the second pass costs one more 16-lane sum).  sum z^2 - n mean^2 in fp32 cancels catastrophically for a
+            // channel with |mean| >> std (relative error ~1e-7 mean^2 / var in rstd, every gradient and running_var); torch uses Welford
             s1 = wave_group_sum(s1, 16);                         // over the 16 pixel-group lanes that share this output channel
-            s2 = wave_group_sum(s2, 16);
-            if (ln == 0) { s_sum[(pw * 2 + 0) * g.hidp + out] = s1; s_sum[(pw * 2 + 1) * g.hidp + out] = s2; }
+            const float mw_ = n_wave > 0 ? s1 / static_cast<float>(n_wave) : 0.f;
+            float m2 = 0.f;
+            if (px_ok) {
+#pragma unroll
+              for (int r = 0; r < VEC; ++r) { const float d = acc[t][r][v] - mw_; m2 += d * d; }
+            }
+            m2 = wave_group_sum(m2, 16);
+            if (ln == 0) { s_sum[(pw * 2 + 0) * g.hidp + out] = s1; s_sum[(pw * 2 + 1) * g.hidp + out] = m2; }
           }
         }
       }
@@ -301,13 +311,20 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
   __syncthreads();
   TRACE_MARK(A.trace, gid, 10);                                 // stores complete
 #endif
-  if (!GX && g.training) {                                      // tile sums of z and z^2 per output channel
+  if (!GX && g.training) {                                      // this tile's (sum, M2 about the tile mean) per output channel
     __syncthreads();
     float* part = A.c.part + static_cast<size_t>(wg) * 2 * g.hidp;
-    for (int i = tid; i < 2 * g.hidp; i += kBlock) {
-      float s = 0.f;
-      for (int w = 0; w < PW; ++w) s += s_sum[w * 2 * g.hidp + i];
-      part[i] = s;
+    for (int i = tid; i < g.hidp; i += kBlock) {
+      float n = 0.f, S = 0.f, M2 = 0.f;
+      for (int w = 0; w < PW; ++w) {                            // the pixel waves' partials, combined pairwise (Chan et al.), fixed order
+        const float nb = static_cast<float>(max(0, min(WPX, g.HW - (tile * A.tile_px + w * WPX))));
+        if (nb > 0.f) {
+          const float Sb = s_sum[(w * 2 + 0) * g.hidp + i], Mb = s_sum[(w * 2 + 1) * g.hidp + i];
+          if (n == 0.f) { S = Sb; M2 = Mb; n = nb; }
+          else { const float d = Sb / nb - S / n; M2 += Mb + d * d * (n * nb / (n + nb)); S += Sb; n += nb; }
+        }
+      }
+      part[i] = S; part[g.hidp + i] = M2;
     }
   }
 }
@@ -323,15 +340,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MTW == 
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_head_stats: batch statistics of z per hidden channel from the tile partials (fixed order, double accumulation), BatchNorm's
 //   running-statistics update (segmentation.py:83 -> torch BatchNorm2d: biased variance for the normalisation, unbiased for the
-//   running estimate, momentum m).  Eval mode: mean / rstd from the running statistics.  Workgroup = 8 channels (16 sums) x 16 strides.
+//   running estimate, momentum m).  Eval mode: mean / rstd from the running statistics.  Workgroup = one channel, 256 strides over the tiles.
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_head_stats(const Group<HeadArgs> G) {
-  __shared__ double red[kBlock];
+  __shared__ double red[2][kBlock];
   int local;
   const int l = find_level(G, blockIdx.x, local);
   const HeadArgs& A = G.lv[l];
   const HeadGeo& g = A.g;
-  const int tid = threadIdx.x, which = tid & 1, gq = tid >> 1;  // workgroup = one hidden channel: 2 sums x 128 strides over the tiles
+  const int tid = threadIdx.x;                                  // workgroup = one hidden channel: 256 strides over the tiles
   const int j = local;
   // everything thread 0 needs for the tail is requested NOW, beside the partials (after the reduction each load would be a round trip
   // of its own: the stores to the running statistics between them keep the compiler from batching)
@@ -345,32 +362,42 @@ __global__ __launch_bounds__(kBlock) void k_head_stats(const Group<HeadArgs> G) 
     for (int q = 0; q < 9; ++q) whv[q] = A.p.wh[static_cast<size_t>(j) * 9 + q];
     if (j == 0 && A.p.nbt && g.training) nbt0 = *A.p.nbt;
   }
-  double acc = 0.0;
+  // per tile w: (S_w, M2_w about the tile's own mean, n_w pixels).  Over all tiles:  sum (x - m)^2 = sum_w M2_w + sum_w S_w^2 / n_w - S^2 / n,
+  // accumulated in double (the last two terms cancel to ~1e-16 mean^2 / var relative, harmless)
+  double acc1 = 0.0, acc2 = 0.0;
   if (g.training) {
-    const float* p = A.c.part + static_cast<size_t>(which) * g.hidp + j;
+    const float* p = A.c.part + j;
+    const size_t stride = static_cast<size_t>(2) * g.hidp;
     constexpr int U = 4;
-    int w = gq;
-    for (; w + (U - 1) * 128 < A.nwg; w += U * 128) {           // U independent loads in flight
-      float v[U];
+    auto tile_n = [&](int w) { const int t = w % A.tiles_per_sample; return static_cast<double>(min(A.tile_px, g.HW - t * A.tile_px)); };
+    int w = tid;
+    for (; w + (U - 1) * kBlock < A.nwg; w += U * kBlock) {     // U independent load pairs in flight
+      float sv[U], mv[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = p[static_cast<size_t>(w + u * 128) * 2 * g.hidp];
+      for (int u = 0; u < U; ++u) { sv[u] = p[(w + u * kBlock) * stride]; mv[u] = p[(w + u * kBlock) * stride + g.hidp]; }
 #pragma unroll
-      for (int u = 0; u < U; ++u) acc += static_cast<double>(v[u]);
+      for (int u = 0; u < U; ++u) {
+        const double sd = static_cast<double>(sv[u]);
+        acc1 += sd; acc2 += static_cast<double>(mv[u]) + sd * sd / tile_n(w + u * kBlock);
+      }
     }
-    for (; w < A.nwg; w += 128) acc += static_cast<double>(p[static_cast<size_t>(w) * 2 * g.hidp]);
+    for (; w < A.nwg; w += kBlock) {
+      const double sd = static_cast<double>(p[w * stride]);
+      acc1 += sd; acc2 += static_cast<double>(p[w * stride + g.hidp]) + sd * sd / tile_n(w);
+    }
   }
-  red[tid] = acc;
+  red[0][tid] = acc1; red[1][tid] = acc2;
   __syncthreads();
-  for (int o = kBlock >> 1; o >= 2; o >>= 1) {                  // fixed-order tree; the two sums stay on even / odd slots
-    if (tid < o) red[tid] += red[tid + o];
+  for (int o = kBlock >> 1; o >= 1; o >>= 1) {                  // fixed-order tree
+    if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
     __syncthreads();
   }
   if (tid == 0) {
     float mean, var;
     if (g.training) {
       const double n = static_cast<double>(g.B) * g.HW;
-      const double m = red[0] / n;
-      double v = red[1] / n - m * m;
+      const double m = red[0][0] / n;
+      double v = (red[1][0] - red[0][0] * m) / n;                // biased variance: sum (x - m)^2 / n
       if (v < 0.0) v = 0.0;
       mean = static_cast<float>(m); var = static_cast<float>(v);
       const double unb = n > 1.0 ? v * n / (n - 1.0) : v;
@@ -407,17 +434,27 @@ constexpr int kHeadOutPxMax = 256;
 constexpr int kHeadOutCst = 12;                                 // LDS floats per channel of constants: scale, shift, 9 weights (+1 pad)
 // run length / channels per wave and pass of a level, and the LDS row of one staged channel: the run, W+1 pixels either side and the
 // slack of starting on a 16-byte boundary
-__host__ __device__ inline void head_out_shape(int hid, int& out_px, int& jo) {
+__host__ __device__ inline int head_out_row(int out_px, int W) { return (out_px + 2 * (W + 1) + 3 + 3) & ~3; }
+constexpr int kHeadOutLds = 48 * 1024;                          // LDS budget of a k_head_out workgroup (4 waves x jo rows + constants)
+__host__ __device__ inline size_t head_out_lds(int out_px, int jo, int W) {
+  return static_cast<size_t>(4) * jo * (head_out_row(out_px, W) + kHeadOutCst) * sizeof(float);
+}
+// Wide images (W >= ~100 at hidden > 32: 1280-px inputs at m/l/x widths) would not fit the budget with the run length picked from the
+// channel count alone -- the halo of W+1 pixels either side dominates a short run: they take the longest run and fewer channels per pass
+// (more passes instead of a launch failure).  jo = 0: even one channel per pass does not fit (W > ~1390): the caller reports E_SHAPE.
+__host__ __device__ inline void head_out_shape(int hid, int W, int& out_px, int& jo) {
   const int cw = (hid + 3) >> 2;
   if (cw <= 4) { out_px = 256; jo = 4; } else if (cw <= 8) { out_px = 128; jo = 8; } else { out_px = 64; jo = 16; }
+  if (head_out_lds(out_px, jo, W) <= kHeadOutLds) return;
+  out_px = 256;
+  for (jo = 4; jo >= 1 && head_out_lds(out_px, jo, W) > kHeadOutLds; jo >>= 1) {}
 }
-__host__ __device__ inline int head_out_row(int out_px, int W) { return (out_px + 2 * (W + 1) + 3 + 3) & ~3; }
 template <typename T, int VEC>
 __device__ __forceinline__ void head_out_body(const HeadArgs& A, const int wg, float* smem) {
   const HeadGeo& g = A.g;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   int out_px, jo;
-  head_out_shape(g.hid, out_px, jo);
+  head_out_shape(g.hid, g.W, out_px, jo);
   const int ppl = out_px >> 6;                                  // pixels per lane: 4, 2, 1
   const int per = (g.HW + out_px - 1) / out_px;
   const int b = wg / per, p0 = (wg - b * per) * out_px;

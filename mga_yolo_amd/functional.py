@@ -556,6 +556,8 @@ class _HeadFn(torch.autograd.Function):
             hid = w1.shape[0]
             if tuple(w1.shape[:2]) != (hid, Cc) or tuple(wh.shape) != (1, hid, 3, 3) or bh.numel() != 1 or gamma.numel() != hid:
                 raise ValueError(f"mask_head: parameter shapes do not match C={Cc}, hidden={hid} (out_channels must be 1)")
+            if training and B * H * W == 1:                     # torch.nn.functional.batch_norm refuses this too (no variance from one value)
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
             xc = _ready(x)
             pc = [_ready(t.float() if t.dtype != torch.float32 else t) for t in (w1, gamma, beta, wh, bh)]
             for t in (rmean, rvar):

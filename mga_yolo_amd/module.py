@@ -272,6 +272,9 @@ def _eca_host_forward(x, mask, w, beta, cfg: EcaConfig) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------------------
 # MGAMaskHead: mirror of mga_yolo/nn/modules/segmentation.py:34-127
 # ---------------------------------------------------------------------------------------------------------
+_HEAD_MAX_W = 1390   # widest image row the mask-head kernels stage in LDS (csrc/head.cuh: head_out_shape); wider features run torch ops
+
+
 class _HeadCfg:
     """Attribute bag with the reference dataclass's field names (segmentation.py:35-53)."""
 
@@ -337,10 +340,21 @@ class MGAMaskHead(nn.Module):
         return bool(bn.affine and bn.track_running_stats and bn.momentum is not None and bn.running_mean is not None)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:         # (B, C_in, H, W) -> (B, C_out, H, W) logits
-        if x.is_cuda and self.hip_path():
+        if x.is_cuda and self.hip_path() and x.shape[-1] <= _HEAD_MAX_W:
             conv, bn = self.proj._modules["0"], self.proj._modules["1"]
-            return mask_head(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+            rm, rv = bn.running_mean, bn.running_var
+            if rm.dtype != torch.float32 or rv.dtype != torch.float32:
+                # a halved module: the validator calls model.half() on the EMA copy whenever AMP is on (U/engine/validator.py:147-149),
+                # and half=True predict does the same.  The kernels keep statistics in fp32: in eval mode nothing is written back, so
+                # fp32 copies serve; a TRAINING module with half-precision buffers (not something the reference trainer produces)
+                # runs the containers' torch ops, which update the buffers in their own precision
+                if self.training:
+                    return self.head(self.proj(x))
+                rm, rv = rm.float(), rv.float()
+            return mask_head(x, conv.weight, bn.weight, bn.bias, rm, rv, bn.num_batches_tracked,
                              self.head.weight, self.head.bias, eps=bn.eps, momentum=bn.momentum, training=self.training)
+        if x.is_cuda and self.hip_path():                         # a shape outside the kernels' range (rows wider than _HEAD_MAX_W)
+            return self.head(self.proj(x))
         if x.is_cuda and not self.__dict__.get("_warned_variant"):
             import warnings
             warnings.warn("MGAMaskHead: constructor variant outside the HIP path (norm / act / dropout / out_channels); running torch ops")

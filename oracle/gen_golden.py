@@ -84,6 +84,19 @@ def data(B, C, H, W, seed=1234, mask_kind="randn", mask3d=False, x_kind="randn")
         mask = torch.rand(ms, generator=g)
     elif mask_kind == "zeros":
         mask = torch.zeros(ms)
+    elif mask_kind == "boundary":          # logits within a few ulp of the selector's threshold, scattered over a random field; the
+        mask = r.clone()                   # feature is largest exactly there, so a pixel selected (or not) by mistake moves max / arg-max
+        t = 1.5 * 2.0 ** -24               # sigmoid(m) > 0.5 in fp32 <=> m > 1.5 * 2^-24
+        vals = [0.0, -0.0, t, -t, 2.0 ** -22, -2.0 ** -22, 2.0 ** -23, 2.0 ** -24, 2.0 ** -25, 2.0 ** -26, -2.0 ** -26, 1e-40, -1e-40]
+        vals += [float(torch.nextafter(torch.tensor(t), torch.tensor(1.0))), float(torch.nextafter(torch.tensor(t), torch.tensor(0.0))),
+                 float(torch.nextafter(torch.tensor(2.0 ** -23), torch.tensor(1.0))), 3.0 * 2.0 ** -25, 5.0 * 2.0 ** -26, 1e-7, 8.9e-8, 9.0e-8]
+        flat = mask.view(-1)
+        pos = torch.randperm(flat.numel(), generator=g)[: 6 * len(vals)]
+        flat[pos] = torch.tensor(vals, dtype=torch.float32).repeat(6)
+        xb = x.view(B, C, -1)
+        hw = xb.shape[-1]
+        for q, pp in enumerate(pos.tolist()):          # channel (q mod C) peaks at this pixel
+            xb[pp // hw, q % C, pp % hw] = 6.0 + 0.01 * q
     elif mask_kind == "mixed":            # per-sample branches: normal / nothing selected / tiny
         mask = r.clone()
         mask[1] = -mask[1].abs() - 0.1
@@ -117,6 +130,7 @@ CASES = [
     ("stride_probe",   1, 64, 32, 32, dict(),                                 dict(x_kind="zeros", mask_kind="zeros")),
     ("p5_like",        2, 256, 5,  5, dict(randomize=17),                     dict()),
     ("w1_tail",        2, 16,  6, 10, dict(randomize=19),                     dict(mask_kind="sparse")),
+    ("boundary_logits", 2, 24, 12, 20, dict(randomize=23),                    dict(mask_kind="boundary")),
 ]
 
 # full-size shapes: only checksums are kept (x is 3-52 MB)
@@ -205,7 +219,11 @@ def main():
     old = json.load(open(path)) if (big_only and os.path.exists(path)) else {}
     if big_only:
         torch.set_num_threads(8)       # checksums only: 1e-4-level comparisons do not depend on the summation order
-    for name, B, C, H, W, mk, dk in ([] if big_only else CASES):
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]      # --only=NAME: add a case, leave the committed ones alone
+    if only:
+        old = json.load(open(path))
+        index = dict(old.get("cases", {}))
+    for name, B, C, H, W, mk, dk in ([] if big_only else [c for c in CASES if not only or c[0] in only]):
         m = build(C, **mk)
         x, mask, gy = data(B, C, H, W, **dk)
         out, sd = run(m, x, mask, gy)
@@ -222,7 +240,7 @@ def main():
         index[name] = dict(shape=[B, C, H, W], **meta, ysum=float(out["y"].double().sum()))
         print(f"case {name:16s} y.sum={index[name]['ysum']:.6f}")
 
-    for name, B, C, H, W, mk, dk in ([] if big_only else ECA_CASES):
+    for name, B, C, H, W, mk, dk in ([] if (big_only or only) else ECA_CASES):
         m = build_eca(C, **mk)
         x, mask, gy = data(B, C, H, W, **dk)
         out, sd = run_eca(m, x, mask, gy)
@@ -242,7 +260,7 @@ def main():
 
     sums = dict(old.get("big", {}))
     for name, B, C, H, W, mkind, recipe in BIG:
-        if big_only and name in sums:
+        if (big_only or only) and name in sums:
             continue
         m = build(C)
         x, mask, gy = data(B, C, H, W, mask_kind=mkind)
@@ -255,7 +273,8 @@ def main():
                           **{k_: checksum(v) for k_, v in out.items()})
         print(f"big  {name:16s} y.sum={sums[name]['y']['sum']:.6f} |gx|={sums[name]['gx']['abs']:.6f}")
     with open(path, "w") as f:
-        json.dump(dict(cases=old.get("cases", index) if big_only else index, big=sums, torch=old.get("torch", torch.__version__)),
+        json.dump(dict(cases=old.get("cases", index) if big_only else index, big=sums,
+                       torch=old.get("torch", torch.__version__) if (big_only or only) else torch.__version__),
                   f, indent=1, sort_keys=True)
 
 

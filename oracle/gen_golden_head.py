@@ -51,10 +51,17 @@ CASES = [
     ("wide",        1,  64,  16,  3, 40, dict(randomize=21)),
     ("hid128",      1, 512, 128,  4,  4, dict(randomize=23)),
     ("stride_probe", 1, 64,  16, 32, 32, dict(x_kind="zeros", training=False)),          # parse_model's eval-mode zero-image probe (U/nn/tasks.py:413-429)
+    ("hid192",      1, 768, 192,  4,  5, dict(randomize=25)),                           # x-scale P4/P5 width: hidden > 128 (four-tile GEMM template, its own launch)
+    ("dc_offset",   2,  64,  16, 12, 12, dict(randomize=27, x_offset=50.0)),            # |mean| >> std per channel: variance by sum z^2 - n mean^2 would cancel
+    ("w160_hid64",  1,  64,  64,  3, 160, dict(randomize=29)),                          # 1280-px P3 row width at m/l hidden width: the 3x3 kernels' LDS staging bound
 ]
 BIG = [
     ("cfg2_p3", 32,  64, 16, 80, 80), ("cfg2_p4", 32, 128, 32, 40, 40), ("cfg2_p5", 32, 256, 64, 20, 20),
     ("cfg3_p3", 32, 128, 32, 80, 80), ("cfg3_p4", 32, 256, 64, 40, 40), ("cfg3_p5", 32, 512, 128, 20, 20),
+    # BASELINE configs[4] (YOLOv8l + seg head, mixed 640 / 1280, bf16): the reference runs in fp32 on the bf16-rounded inputs;
+    # configs[3]'s "x192" P3 at 1280 px (hidden 48: not a multiple of 16)
+    ("cfg5_640_p3", 8, 256, 64, 80, 80, "bf16"), ("cfg5_640_p4", 8, 512, 128, 40, 40, "bf16"), ("cfg5_640_p5", 8, 512, 128, 20, 20, "bf16"),
+    ("cfg5_1280_p3", 4, 256, 64, 160, 160, "bf16"), ("cfg4_p3_192", 8, 192, 48, 160, 160),
 ]
 
 
@@ -78,11 +85,13 @@ def build(C, hid, seed=0, randomize=None, eps=None, momentum=None, training=True
     return m
 
 
-def data(B, C, H, W, seed=1234, x_kind="randn"):
+def data(B, C, H, W, seed=1234, x_kind="randn", x_offset=0.0):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, C, H, W, generator=g)
     if x_kind == "zeros":
         x = torch.zeros(B, C, H, W)
+    if x_offset:
+        x = x + x_offset
     gl = torch.randn(B, 1, H, W, generator=g)
     return x, gl
 
@@ -111,9 +120,11 @@ def checksum(tn):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    for name, B, C, hid, H, W, kw in CASES:
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]      # --only=NAME[,NAME]: add cases / checksums, leave the committed ones alone
+    only = [n for a in only for n in a.split(",")]
+    for name, B, C, hid, H, W, kw in [c for c in CASES if not only or c[0] in only]:
         m = build(C, hid, **kw)
-        x, gl = data(B, C, H, W, x_kind=kw.get("x_kind", "randn"))
+        x, gl = data(B, C, H, W, x_kind=kw.get("x_kind", "randn"), x_offset=kw.get("x_offset", 0.0))
         out, before = run(m, x, gl)
         arrays = dict(x=x.numpy(), g_logits=gl.numpy())
         for k, v in before.items():
@@ -126,14 +137,20 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"head_{name}.npz"), **arrays)
         print(f"head {name:14s} logits.sum={float(out['logits'].double().sum()):.6f} |gx|={float(out['gx'].abs().sum()):.6f}")
     torch.set_num_threads(8)
-    sums = {}
-    for name, B, C, hid, H, W in BIG:
+    path = os.path.join(OUT, "head_checksums.json")
+    sums = dict(json.load(open(path))["big"]) if only else {}
+    for name, B, C, hid, H, W, *recipe in BIG:
+        if only and (name in sums or name not in only):
+            continue
         m = build(C, hid, eps=1e-3, momentum=0.03)
         x, gl = data(B, C, H, W)
+        if recipe == ["bf16"]:
+            x, gl = x.bfloat16().float(), gl.bfloat16().float()
         out, _ = run(m, x, gl)
-        sums[name] = dict(shape=[B, C, hid, H, W], eps=1e-3, momentum=0.03, **{k: checksum(v.float()) for k, v in out.items() if k != "num_batches_tracked"})
+        sums[name] = dict(shape=[B, C, hid, H, W], eps=1e-3, momentum=0.03, recipe=(recipe[0] if recipe else "fp32"),
+                          **{k: checksum(v.float()) for k, v in out.items() if k != "num_batches_tracked"})
         print(f"big  {name:10s} logits.sum={sums[name]['logits']['sum']:.6f} |gx|={sums[name]['gx']['abs']:.6f}")
-    with open(os.path.join(OUT, "head_checksums.json"), "w") as f:
+    with open(path, "w") as f:
         json.dump(dict(big=sums, torch=torch.__version__), f, indent=1, sort_keys=True)
 
 

@@ -63,6 +63,19 @@ def synth(B, C, H, W, seed=1234, mask_kind="randn", x_kind="randn", mask3d=False
         mask = torch.rand(ms, generator=g)
     elif mask_kind == "zeros":
         mask = torch.zeros(ms)
+    elif mask_kind == "boundary":          # logits within a few ulp of the selector's threshold, scattered over a random field; the
+        mask = r.clone()                   # feature is largest exactly there, so a pixel selected (or not) by mistake moves max / arg-max
+        t = 1.5 * 2.0 ** -24               # sigmoid(m) > 0.5 in fp32 <=> m > 1.5 * 2^-24
+        vals = [0.0, -0.0, t, -t, 2.0 ** -22, -2.0 ** -22, 2.0 ** -23, 2.0 ** -24, 2.0 ** -25, 2.0 ** -26, -2.0 ** -26, 1e-40, -1e-40]
+        vals += [float(torch.nextafter(torch.tensor(t), torch.tensor(1.0))), float(torch.nextafter(torch.tensor(t), torch.tensor(0.0))),
+                 float(torch.nextafter(torch.tensor(2.0 ** -23), torch.tensor(1.0))), 3.0 * 2.0 ** -25, 5.0 * 2.0 ** -26, 1e-7, 8.9e-8, 9.0e-8]
+        flat = mask.view(-1)
+        pos = torch.randperm(flat.numel(), generator=g)[: 6 * len(vals)]
+        flat[pos] = torch.tensor(vals, dtype=torch.float32).repeat(6)
+        xb = x.view(B, C, -1)
+        hw = xb.shape[-1]
+        for q, pp in enumerate(pos.tolist()):          # channel (q mod C) peaks at this pixel
+            xb[pp // hw, q % C, pp % hw] = 6.0 + 0.01 * q
     elif mask_kind == "mixed":
         mask = r.clone()
         mask[1] = -mask[1].abs() - 0.1

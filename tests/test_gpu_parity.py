@@ -141,9 +141,13 @@ def test_full_size_checksums_vs_reference(F, checksums, name):
                                              ((4, 192, 40, 40), "mixed"), ((2, 384, 20, 20), "randn"), ((3, 48, 17, 17), "mixed"),
                                              ((1, 256, 160, 160), "sparse"), ((2, 512, 40, 40), "randn"), ((1, 768, 20, 20), "mixed"),
                                              ((5, 64, 24, 40), "mixed"), ((9, 32, 6, 10), "randn"), ((1, 1, 1, 1), "randn"),
-                                             ((2, 3, 2, 3), "randn"), ((1, 16, 1, 37), "sparse"), ((11, 24, 13, 4), "mixed")])
+                                             ((2, 3, 2, 3), "randn"), ((1, 16, 1, 37), "sparse"), ((11, 24, 13, 4), "mixed"),
+                                             # BASELINE configs[2] (YOLOv8s, 32 images per GPU) at FULL batch and configs[3]'s P4 (8 x 512 x 80 x 80):
+                                             # twice config 2's workgroups per launch; a wrong tile or halo shows here element by element
+                                             ((32, 128, 80, 80), "sparse"), ((32, 256, 40, 40), "randn"), ((32, 512, 20, 20), "sparse"),
+                                             ((8, 512, 80, 80), "sparse")])
 def test_full_size_vs_oracle_live(F, shape, mask_kind):
-    """Same seeded inputs through the oracle (CPU) and the HIP path, element-wise, at config-2 sizes and the odd shapes."""
+    """Same seeded inputs through the oracle (CPU) and the HIP path, element-wise, at config-2 / config-3 sizes and the odd shapes."""
     B, C, H, W = shape
     if mask_kind == "mixed" and B < 2:
         mask_kind = "randn"
@@ -165,6 +169,10 @@ def test_full_size_vs_oracle_live(F, shape, mask_kind):
         e = rel_err(g[k], g_o[k])
         if not e < TOL:
             report.append(f"{k} {e:.3e}")
+    # every ELEMENT of the feature-sized outputs (conftest.elem_err: own-value relative with a floor of 1e-3 of the scale)
+    for k, got, want in (("y", y, y_o), ("gx", g["gx"], g_o["gx"]), ("gmask", g["gmask"], g_o["gmask"])):
+        if want is not None and not elem_err(got, want) < 1e-3:
+            report.append(f"{k} element-wise {elem_err(got, want):.3e}")
     assert not report, "; ".join(report)
 
 
@@ -341,6 +349,7 @@ def test_plan_executor_matches_oracle_with_and_without_projection_planes(F, want
 @pytest.mark.parametrize("shapes,with_mask,fused", [
     ([(4, 64, 16, 16), (4, 128, 8, 8), (4, 256, 4, 4)], True, True),
     ([(32, 64, 80, 80), (32, 128, 40, 40), (32, 256, 20, 20)], True, True),  # BASELINE configs[1]: every CU busy, real waits
+    ([(32, 128, 80, 80), (32, 256, 40, 40), (32, 512, 20, 20)], True, True), # BASELINE configs[2] per GPU: twice the workgroups, several resident rounds
     ([(3, 48, 17, 17), (5, 24, 9, 7)], True, True),                        # scalar (VEC=1) path, ragged, different B per level
     ([(9, 64, 40, 40), (9, 64, 20, 20)], False, True),                     # no mask; B not a multiple of the 8 XCDs
     ([(2, 256, 6, 160), (2, 64, 12, 80)], True, False),                    # a tile narrower than a row (64 px < W = 160): the group falls back
@@ -733,3 +742,34 @@ def test_fold_counters_survive_a_half_finished_backward(F):
         tiles, convs = sync[nf + 4 + Bn:nf + 4 + Bn + nf], sync[nf + 4 + Bn + nf:]
         assert set(tiles.unique().tolist()) <= {0, 5} and int(tiles.max()) == 5      # fold_active's launch + 3 + 1 folded launches
         assert set(convs.unique().tolist()) <= {0, 5} and int(convs.max()) == 5
+
+
+def test_stale_scratch_size_after_a_knob_change_raises_instead_of_faulting(F, monkeypatch):
+    """Round 2's GPU abort (rc 134): a scratch size cached across mgacbam_reload_env() was too small for the new launch geometry and the
+    kernels wrote out of bounds.  ABI 14: the plan's buffers travel with their capacities, the library recomputes the requirement under
+    the current knobs and refuses (MGACBAM_E_SIZE) -- nothing is launched; with the knobs restored the same plan runs and is correct."""
+    from mga_yolo_amd import _lib
+    from mga_yolo_amd.plan import PyramidPlan
+    shapes = [(4, 64, 40, 40)]
+    x, mask, gy = synth(4, 64, 40, 40, seed=31)
+    p = O.Params.default_init(64, seed=2)
+    plan = PyramidPlan(shapes, [(p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta)], [F.BlockConfig(hidden=p.w1.shape[0])])
+    plan.x[0].copy_(x); plan.mask[0].copy_(mask); plan.gy[0].copy_(gy)
+    plan.forward(); plan.backward()
+    torch.cuda.synchronize()
+    ref_gx = plan.gx[0].clone()
+    monkeypatch.setenv("MGACBAM_CHAN_TX", "1")                    # one pixel vector per tile: ~16x the tile partials
+    _lib.load().mgacbam_reload_env()                              # the raw entry point: the plan keeps its (now stale) buffer sizes
+    try:
+        plan.forward()
+        with pytest.raises(RuntimeError, match="too small"):
+            plan.backward()
+        torch.cuda.synchronize()
+    finally:
+        monkeypatch.undo()
+        _lib.reload_env()
+    plan.forward(); plan.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(plan.gx[0], ref_gx)
+    y_o, c = O.forward(x, mask, p)
+    assert rel_err(plan.gx[0], O.backward(gy, x, mask, p, O.Config(), c)["gx"]) < TOL

@@ -30,8 +30,17 @@ def load_head_golden(name):
 GRAD_KEYS = ("gx", "gw1", "ggamma", "gbeta", "gwh", "gbh")
 
 
+# Entries the REFERENCE's own fp32 arithmetic cannot pin to the usual bar.  dc_offset (features = N(0,1) + 50: per-channel mean^2 / var of
+# z ~ 1e4, the case that exposes a cancelling BatchNorm variance): dW1 = sum g_z x with sum g_z = 0 and x ~ 50 is a difference of large
+# terms; against a float64 evaluation of the same graph the reference's stored dW1 is 9.9e-5 off and a plain fp32 einsum 1.8e-4
+# (measured when the golden was made), everything else 5e-6.  Its dW1 is therefore compared at 5e-4; all other entries at the bar.
+LOOSE = {("dc_offset", "gw1"): 5e-4}
+_CASE = [None]
+
+
 def _close(got, want, tol, what):
     # relative to the tensor's scale, with an absolute floor for all-zero expectations (stride probe: logits are exactly the bias)
+    tol = max(tol, LOOSE.get((_CASE[0], what), 0.0))
     scale = float(want.double().abs().max())
     err = float((got.double() - want.double()).abs().max())
     assert err <= tol * max(scale, 1e-6), (what, err, scale)
@@ -40,6 +49,7 @@ def _close(got, want, tol, what):
 @pytest.mark.parametrize("name", head_golden_names())
 def test_oracle_matches_the_reference_golden(name):
     d = load_head_golden(name)
+    _CASE[0] = name
     m = d["meta"]
     p = HO.HeadParams.from_state_dict(d["params"], eps=m["eps"], momentum=m["momentum"])
     logits, c = HO.forward(d["x"], p, training=m["training"])
@@ -84,6 +94,7 @@ def _check_module(d, m, dev, tol):
 @pytest.mark.parametrize("name", head_golden_names())
 def test_module_host_path_matches_the_reference_golden(name):
     d = load_head_golden(name)
+    _CASE[0] = name
     _check_module(d, _module_from_golden(d), "cpu", 2e-5)
 
 
@@ -117,6 +128,7 @@ def test_device_path_matches_the_reference_golden(built_lib, name):
     """HIP path (C ABI mgahead_forward / mgahead_backward through the module) vs what the reference's own MGAMaskHead produced:
     logits, every gradient, BatchNorm running statistics and num_batches_tracked."""
     d = load_head_golden(name)
+    _CASE[0] = name
     m = _module_from_golden(d, "cuda")
     assert m.hip_path()
     _check_module(d, m, "cuda", TOL)
@@ -124,11 +136,16 @@ def test_device_path_matches_the_reference_golden(built_lib, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["cfg2_p3", "cfg2_p4", "cfg2_p5", "cfg3_p3", "cfg3_p4", "cfg3_p5"])
+@pytest.mark.parametrize("name", ["cfg2_p3", "cfg2_p4", "cfg2_p5", "cfg3_p3", "cfg3_p4", "cfg3_p5",
+                                  "cfg5_640_p3", "cfg5_640_p4", "cfg5_640_p5", "cfg5_1280_p3", "cfg4_p3_192"])
 def test_device_full_size_checksums_vs_reference(built_lib, name):
+    """BASELINE configs[1], [2] and the mask-head leg of configs[3] / [4] (YOLOv8l widths C 256 / 512 / 512, hidden 64 / 128 / 128, 640 and
+    1280 px; the reference evaluated in fp32 on bf16-rounded inputs, the device path fed bf16 tensors)."""
     from mga_yolo_amd import MGAMaskHead
     ref = json.load(open(os.path.join(GOLDEN, "head_checksums.json")))["big"][name]
     B, C, hid, H, W = ref["shape"]
+    bf16 = ref.get("recipe") == "bf16"
+    tol = 1e-3 if bf16 else TOL                                    # (the bar of the bf16 MaskCBAM checksums, test_gpu_parity.py)
     torch.manual_seed(0)
     m = MGAMaskHead(C, hid)
     m.proj[1].eps, m.proj[1].momentum = ref["eps"], ref["momentum"]
@@ -136,8 +153,11 @@ def test_device_full_size_checksums_vs_reference(built_lib, name):
     g = torch.Generator().manual_seed(1234)                        # the recipe of oracle/gen_golden_head.py:data()
     x = torch.randn(B, C, H, W, generator=g)
     gl = torch.randn(B, 1, H, W, generator=g)
+    if bf16:
+        x, gl = x.bfloat16(), gl.bfloat16()
     xd = x.cuda().requires_grad_(True)
     y = m(xd)
+    assert y.dtype == x.dtype
     y.backward(gl.cuda())
     p = dict(m.named_parameters())
     got = dict(logits=y.detach(), gx=xd.grad, gw1=p["proj.0.weight"].grad, ggamma=p["proj.1.weight"].grad, gbeta=p["proj.1.bias"].grad,
@@ -147,7 +167,7 @@ def test_device_full_size_checksums_vs_reference(built_lib, name):
         c = checksum(v.float())
         scale = ref[k]["abs"] + 1e-12
         for f in ("sum", "wsum", "abs"):
-            if not abs(c[f] - ref[k][f]) <= TOL * scale:
+            if not abs(c[f] - ref[k][f]) <= tol * scale:
                 report.append(f"{k}.{f}: got {c[f]:.6f} want {ref[k][f]:.6f}")
     assert not report, f"{name}: " + "; ".join(report)
     # run-to-run reproducibility (fixed-order sums, no float atomics)
@@ -176,6 +196,32 @@ def test_device_half_precision_io(built_lib, dtype, tol):
     assert xd.grad.dtype == dtype
     assert rel_err(y.float(), lo) < tol and rel_err(xd.grad.float(), go["gx"]) < tol
     assert rel_err(m.proj[0].weight.grad.reshape(32, 128), go["gw1"]) < tol and rel_err(m.head.weight.grad, go["gwh"]) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+def test_device_halved_module_in_eval_mode(built_lib, dtype, tol):
+    """The validator calls model.half() on the EMA copy whenever AMP is on (U/engine/validator.py:147-149; half=True predict does the
+    same): every parameter AND the BatchNorm running statistics are half precision then.  The HIP path must serve that module
+    (fp32 copies of the statistics: eval mode writes nothing back) and agree with the fp32 oracle on the rounded state."""
+    from mga_yolo_amd import MGAMaskHead
+    torch.manual_seed(5)
+    m = MGAMaskHead(128, 32)
+    with torch.no_grad():
+        m.proj[1].running_mean.normal_(0.0, 0.3)
+        m.proj[1].running_var.uniform_(0.5, 1.5)
+    m = m.cuda().to(dtype).eval()
+    assert m.hip_path() and m.proj[1].running_mean.dtype == dtype
+    x = torch.randn(3, 128, 20, 20, generator=torch.Generator().manual_seed(8)).to(dtype)
+    with torch.no_grad():
+        y = m(x.cuda())
+    assert y.dtype == dtype and m.proj[1].running_mean.dtype == dtype
+    p = HO.HeadParams.from_state_dict({k: v.detach().float().cpu() for k, v in m.state_dict().items()})
+    lo, _ = HO.forward(x.float(), p, False)
+    assert rel_err(y.float(), lo) < tol
+    # a TRAINING module with half-precision buffers (not something the reference trainer produces) still works: the containers' torch ops
+    m.train()
+    assert m(x.cuda()).shape == y.shape
 
 
 @pytest.mark.gpu
