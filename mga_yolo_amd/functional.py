@@ -287,15 +287,17 @@ class _PyramidFn(torch.autograd.Function):
             L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[xc.dtype]
             L.flags = _lib.BWD_HAVE_PROJ if ctx.meta[l][1] else 0
             hold += [gy, scratch]
-            if gmask is not None:
-                mdtype, mshape = ctx.meta[l][0]
-                gmask = gmask.reshape(mshape).to(mdtype)
             grads += [gx, gmask, *pg]
         with _on_device(dev):
             rc = lib.mgacbam_backward_stages(levels, n, _BWD_STAGES, _raw_stream(dev))
         if rc:
             _lib.check(rc, "mgacbam_backward_stages")
         del hold
+        for l in range(n):                                         # dL/dmask in the mask's own shape / element type -- AFTER the launch that
+            gm = grads[1 + l * SLOTS + 1]                          # writes it (a cast enqueued before it would read unwritten memory: that
+            if gm is not None:                                     # was the case for half-precision masks until the AMP test of round 3)
+                mdtype, mshape = ctx.meta[l][0]
+                grads[1 + l * SLOTS + 1] = gm.reshape(mshape).to(mdtype)
         if _CHECK_HANDOFF:
             _check_status([(ls.buf, ls.key[2:7]) for ls in ctx.leases], "mask_cbam backward")
         return tuple(grads)
@@ -447,13 +449,15 @@ class _EcaFn(torch.autograd.Function):
             L.p = _lib.EcaParams(wc.data_ptr(), bc.data_ptr(), cfg.k, int(cfg.use_sigmoid_mask), cfg.tiny_thr, cfg.eps)
             L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[xc.dtype]
             hold += [gy, scratch]
-            if gmask is not None:
-                mdtype, mshape = ctx.meta[l]
-                gmask = gmask.reshape(mshape).to(mdtype)
             grads += [gx, gmask, gw, gb]
         with torch.cuda.device(dev):
             _lib.check(lib.mgacbam_eca_backward(levels, n, torch.cuda.current_stream(dev).cuda_stream), "mgacbam_eca_backward")
         del hold
+        for l in range(n):                                         # (after the launch that writes it, see _PyramidFn.backward)
+            gm = grads[1 + 4 * l + 1]
+            if gm is not None:
+                mdtype, mshape = ctx.meta[l]
+                grads[1 + 4 * l + 1] = gm.reshape(mshape).to(mdtype)
         return tuple(grads)
 
 

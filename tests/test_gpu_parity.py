@@ -773,3 +773,37 @@ def test_stale_scratch_size_after_a_knob_change_raises_instead_of_faulting(F, mo
     assert torch.equal(plan.gx[0], ref_gx)
     y_o, c = O.forward(x, mask, p)
     assert rel_err(plan.gx[0], O.backward(gy, x, mask, p, O.Config(), c)["gx"]) < TOL
+
+
+@pytest.mark.parametrize("mdtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+def test_half_precision_mask_gets_its_gradient_in_its_own_dtype(F, mdtype, tol):
+    """Under AMP the mask logits arrive in half precision (the mask head's conv runs under autocast): dL/dmask must come back in that
+    dtype with the right VALUES.  Regression: the cast of dL/dmask to the mask's dtype was enqueued before the launch that writes it
+    (it read unwritten memory; invisible with fp32 masks, where the cast is the identity) -- found by the AMP slice test of round 3."""
+    from mga_yolo_amd.functional import EcaConfig, mask_eca
+    B, C, H, W = 4, 64, 20, 20
+    x, mask, gy = synth(B, C, H, W, seed=23)
+    mask = mask.to(mdtype).float()
+    p = O.Params.default_init(C)
+    y_o, ctx = O.forward(x, mask, p)
+    g_o = O.backward(gy, x, mask, p, O.Config(), ctx)
+    for rep in range(3):                                           # (fresh allocations each time: stale contents differ)
+        xd = x.cuda().requires_grad_(True)
+        md = mask.cuda().to(mdtype).requires_grad_(True)
+        ps = [t.cuda() for t in (p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta)]
+        y = F.mask_cbam(xd, md, *ps, F.BlockConfig(hidden=p.w1.shape[0]))
+        torch.cuda.empty_cache()
+        y.backward(gy.cuda())
+        assert md.grad.dtype == mdtype and md.grad.shape == md.shape
+        assert rel_err(md.grad.float(), g_o["gmask"]) < tol and rel_err(xd.grad, g_o["gx"]) < TOL
+    from oracle import maskeca_oracle as EO
+    we = torch.randn(1, 1, 3, generator=torch.Generator().manual_seed(4))
+    be = torch.tensor(0.2)
+    xd = x.cuda().requires_grad_(True)
+    md = mask.cuda().to(mdtype).requires_grad_(True)
+    ye = mask_eca(xd, md, we.cuda(), be.cuda(), EcaConfig(k=3))
+    ye.backward(gy.cuda())
+    xh, mh = x.clone().requires_grad_(True), mask.clone().requires_grad_(True)
+    from mga_yolo_amd.module import _eca_host_forward
+    _eca_host_forward(xh, mh, we, be, EcaConfig(k=3)).backward(gy)
+    assert md.grad.dtype == mdtype and rel_err(md.grad.float(), mh.grad) < tol and rel_err(xd.grad, xh.grad) < TOL
