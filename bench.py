@@ -119,10 +119,12 @@ def time_kernels(plan, reps):
     else:
         bwd = [("bwd.reduce1", plan.backward, Bs["reduce1"]), ("bwd.convT", plan.backward, Bs["convT"])]
     fold_bit = _lib.BWD_FOLD if plan.fold_backward else 0
+    # the two fused launches: streaming workgroups + role workgroups.  With the zero-filled hand-off state (fold_bit) the dWsa tile partials
+    # are the LAST workgroups of the k_bwd_apply launch, as in the real step (one mgacbam_backward call); else leading roles of k_bwd_reduce2
+    wsa_in_apply = Bs["wsa"] if (fold_bit and os.environ.get("MGACBAM_WSA_TAIL", "0") == "1") else 0
     seq = fwd + bwd + [
-           # the two fused launches: streaming workgroups + role workgroups (dWsa partials / parameter gradients)
-           ("bwd.reduce2", plan.backward, Bs["reduce2"] | Bs["wsa"] | _lib.BWD_FUSE),
-           ("bwd.apply", plan.backward, Bs["params"] | Bs["apply"] | _lib.BWD_FUSE | fold_bit)]
+           ("bwd.reduce2", plan.backward, Bs["reduce2"] | (Bs["wsa"] ^ wsa_in_apply) | _lib.BWD_FUSE),
+           ("bwd.apply", plan.backward, Bs["params"] | Bs["apply"] | wsa_in_apply | _lib.BWD_FUSE | fold_bit)]
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(seq) + 1)] for _ in range(reps)]
     for _ in range(3):
         for _, fn, mask in seq:

@@ -131,7 +131,8 @@ typedef struct mgacbam_ctx_layout {
   int64_t sa;       /* (B,HW)   spatial gate                              masked_cbam.py:147 */
   int64_t proj;     /* (B,hid,HW) W1-projection of x, only when hid <= MGACBAM_PROJ_MAX_HIDDEN (else empty)  */
   int64_t sync;     /* int32 hand-off state, generation counters that are never reset: (B, ceil(HW/16)+1) tile flags of MGACBAM_FWD_FUSE
-                       (see there), 4 status words, (B) ca flags, 2 x (B, ceil(HW/16)+1) MGACBAM_BWD_FOLD tile / conv-tile flags */
+                       (see there), 4 status words ([0] time-out, [1] [2] arrival counters of the dWsa tail roles: 0 between calls), (B) ca
+                       flags, 2 x (B, ceil(HW/16)+1) MGACBAM_BWD_FOLD tile / conv-tile flags */
   int64_t total;    /* == mgacbam_ctx_bytes()                                                 */
   int64_t status;   /* int32 status word inside `sync`: 0 = every in-launch hand-off of every call on this ctx completed; non-zero =
                        one timed out (that tile's outputs were poisoned with NaN).  The caller reads these 4 bytes wherever it
@@ -198,7 +199,11 @@ enum {
                                  The counters are never reset, so a backward that stops after this launch leaves a consistent
                                  state.  The conv tiles wait only for lower-numbered workgroups that never wait themselves, so
                                  progress does not depend on residency; a time-out still poisons (NaN g_planes -> gx) and sets
-                                 the status word.  Not part of MGACBAM_BWD_ALL: mgacbam_backward() works on an un-zeroed ctx  */
+                                 the status word.  Not part of MGACBAM_BWD_ALL: mgacbam_backward() works on an un-zeroed ctx.
+                                 Knob MGACBAM_WSA_TAIL=1 (opt-in, measured slower at BASELINE configs[1]): with WSA + PARAMGRAD + APPLY +
+                                 FUSE in the same call the flag also moves the dWsa tile partials from the front of the REDUCE2 launch
+                                 to the END of the APPLY launch, followed by the workgroups that sum them in the fixed order (bitwise
+                                 reproducible) once an arrival counter (status words 1, 2 of ctx.sync, 0 between calls) says so      */
 };
 int mgacbam_forward_stages(const mgacbam_fwd_level_t* levels, int n_levels, int stages, void* stream);
 int mgacbam_backward_stages(const mgacbam_bwd_level_t* levels, int n_levels, int stages, void* stream);

@@ -41,6 +41,7 @@ static int backward_args(const mgacbam_bwd_level_t& L, BwdArgs& A, Sig& sig) {
   A.nconv = A.g.B * conv_tiles(A.t, A.g.H, A.g.W);
   A.nwsa = A.g.B * wsa_tiles(A.t, A.g.H, A.g.W);
   A.nrole = A.nwsa;
+  A.wsa_tail = 0;
   A.npg = params_blocks(A.g);
   A.ncg = 0;
   A.nflag = static_cast<int>(sync_flags(static_cast<size_t>(L.H) * L.W));
@@ -110,8 +111,13 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
     if (int e = launch_status("k_bwd_convT")) return e;
   }
   const bool fuse = (stages & MGACBAM_BWD_FUSE) != 0;
-  const bool fuse_wsa = fuse && (stages & MGACBAM_BWD_REDUCE2) && (stages & MGACBAM_BWD_WSA) && sig.k == 7;
   const bool fuse_pg = fuse && (stages & MGACBAM_BWD_APPLY) && (stages & MGACBAM_BWD_PARAMGRAD);
+  // dWsa tile partials: leading roles of k_bwd_reduce2; or (opt-in knob MGACBAM_WSA_TAIL, measured slower: bwd.cuh) the LAST workgroups
+  // of the k_bwd_apply launch when ctx.sync is the zero-filled hand-off state (MGACBAM_BWD_FOLD's contract: the arrival counters live there)
+  // (a staged caller asks for it by passing MGACBAM_BWD_WSA with the APPLY call instead of the REDUCE2 call: bench.py's per-kernel timing)
+  const bool wsa_tail = fuse_pg && (stages & MGACBAM_BWD_FOLD) && (stages & MGACBAM_BWD_WSA) && sig.k == 7 && knobs().wsa_tail;
+  const bool fuse_wsa = fuse && (stages & MGACBAM_BWD_REDUCE2) && (stages & MGACBAM_BWD_WSA) && sig.k == 7 && !wsa_tail;
+  if (wsa_tail) for (int l = 0; l < n; ++l) { lv[l].wsa_tail = 1; G.lv[l].wsa_tail = 1; }
   if (stages & MGACBAM_BWD_REDUCE2) {  // 3. rest of g_ca (needs g_planes), g_z [+ dWsa partials as role workgroups]
     size_t smem = 0;
     for (int l = 0; l < n; ++l) {
@@ -150,7 +156,7 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
 #undef CALL_R22
     if (int e = launch_status("k_bwd_reduce2")) return e;
   }
-  if ((stages & MGACBAM_BWD_WSA) && !fuse_wsa) {  // 4. dWsa tile partials (depends on stage 1 only)
+  if ((stages & MGACBAM_BWD_WSA) && !fuse_wsa && !wsa_tail) {  // 4. dWsa tile partials (depends on stage 1 only)
     size_t smem = 0;
     for (int l = 0; l < n; ++l) smem = std::max(smem, wsa_smem(lv[l].t, sig.k));
     const int grid = fill([&](const BwdArgs& a) { return a.nwsa; });
@@ -174,8 +180,9 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
     for (int l = 0; l < n; ++l) {
       smem = std::max(smem, bwd_apply_smem(lv[l].g, sig.vec));
       if (fuse_pg) smem = std::max(smem, params_smem(lv[l].g));
+      if (wsa_tail) smem = std::max(smem, wsa_smem(lv[l].t, sig.k));
     }
-    const int grid = fill([&](const BwdArgs& a) { return (fuse_pg ? pad8(a.npg) : 0) + xcd_grid(a.g.B, a.nt); });
+    const int grid = fill([&](const BwdArgs& a) { return (fuse_pg ? pad8(a.npg) : 0) + xcd_grid(a.g.B, a.nt) + (wsa_tail ? a.nwsa + (3 * a.g.k * a.g.k + 3) / 4 : 0); });
 #define CALL_AP2(GM) if (fuse_pg) LAUNCH((k_bwd_apply<TT, VV, GM, true>), grid, smem, st, G); else LAUNCH((k_bwd_apply<TT, VV, GM, false>), grid, smem, st, G)
 #define CALL_AP(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; if (sig.gmask) { CALL_AP2(true); } else { CALL_AP2(false); } }
     DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_AP);

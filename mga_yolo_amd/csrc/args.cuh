@@ -87,6 +87,8 @@ struct BwdArgs {
   int cflag0;   // first flag of the folded transposed-conv tiles in c.sync: [nconv], generation counters like the tile flags
   unsigned spin_limit;
   int vec;      // elements per lane of the tile kernels (TP = chan_tx * vec pixels per tile)
+  int wsa_tail; // 1: the dWsa tile partials and their sums are the LAST workgroups of the k_bwd_apply launch (arrival counters = status
+                // words 1, 2 of c.sync, 0 between calls); 0: k_bwd_reduce2 roles / own launch
   long long* trace;   // MGACBAM_TRACE builds only (tools/trace_gate.py), else nullptr
 };
 

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_reduce1_fold(const Group<BwdArgs
 //   through LDS.  K == 0 (any odd k): one thread per output.
 //   LDS: [g_pre tile][3 plane tiles][items * k partial sums]
 // ---------------------------------------------------------------------------------------------
-template <int K>
+template <int K, bool AGENT = false>   // AGENT: the partials are summed inside the same launch (k_bwd_apply's tail roles): written through
 __device__ __forceinline__ void bwd_wsa_body(const BwdArgs& A, const int local, float* smem) {
   const Geo& g = A.g;
   const int k = K ? K : g.k;
@@ -295,7 +295,8 @@ __device__ __forceinline__ void bwd_wsa_body(const BwdArgs& A, const int local, 
       const int pi = o / KK, j = o - pi * KK;
       float sum = 0.f;
       for (int r = 0; r < c.TH; ++r) sum += accs[(pi * c.TH + r) * KK + j];
-      A.s.gwsa_part[static_cast<size_t>(o) * A.nwsa + local] = sum;
+      if (AGENT) st_agent(A.s.gwsa_part + static_cast<size_t>(o) * A.nwsa + local, sum);
+      else A.s.gwsa_part[static_cast<size_t>(o) * A.nwsa + local] = sum;
     }
   } else {
     for (int o = tid; o < nout; o += kBlock) {
@@ -306,7 +307,8 @@ __device__ __forceinline__ void bwd_wsa_body(const BwdArgs& A, const int local, 
       float sum = 0.f;
       for (int yy = 0; yy < c.TH; ++yy)
         for (int xx = 0; xx < c.TW; ++xx) sum += gg[yy * c.PW + xx] * pp[yy * c.PW + xx];
-      A.s.gwsa_part[static_cast<size_t>(o) * A.nwsa + local] = sum;
+      if (AGENT) st_agent(A.s.gwsa_part + static_cast<size_t>(o) * A.nwsa + local, sum);
+      else A.s.gwsa_part[static_cast<size_t>(o) * A.nwsa + local] = sum;
     }
   }
 }
@@ -549,6 +551,7 @@ __device__ __forceinline__ void bwd_params_body(const BwdArgs& A, const int loca
     return;
   }
   if (local < h + nb2 + nb_wsa) {                                // dWsa: lanes stride the tile partials
+    if (A.wsa_tail) return;                                      // (summed by the last-arriving tail role of this launch instead)
     const int o = (local - h - nb2) * 4 + wave;
     if (o >= kk3) return;
     const float* part = A.s.gwsa_part + static_cast<size_t>(o) * A.nwsa;
@@ -796,6 +799,54 @@ __device__ __forceinline__ void bwd_apply_body(const BwdArgs& A, const int bid, 
 // (amdgpu_waves_per_eu(5) -- 94 instead of 104 VGPRs, 5 instead of 4 workgroups per CU -- was measured: config 2 fp32 57.9 -> 55.8 us,
 //  bf16 37.3 -> 38.5, config 4 200 -> 225 us; not adopted.  tools/trace_gate.py bwd shows the launch as two rounds of
 //  ~5 us prologue + ~19 us streaming per workgroup with HBM saturated during the streaming.)
+// dWsa as TAIL roles of the k_bwd_apply launch (A.wsa_tail): the level's grid is [params roles][streaming][nwsa tile partials][nsum sums].
+// As leading roles of k_bwd_reduce2 the 800 one-tile workgroups (8.6 us each at config 2) held 800 of its 1792 slots first and cost that
+// launch 5.5-7 us (tools/trace_r2.py).  Dispatched behind the last streaming workgroup of the step's LONGEST launch they start when its
+// last resident round does and run in the slots that round leaves free.  dWsa needs g_pre and the forward planes only (complete since
+// k_bwd_reduce1).  Hand-off: every tile role adds to an arrival counter (status word 1 of ctx.sync) once its partials are out; the sum
+// roles (4 outputs each, the fixed order of k_bwd_params: bitwise reproducible) are the very last workgroups, wait for nwsa arrivals --
+// every producer has a lower id and never waits, so progress does not depend on residency; the wait is bounded like every other -- and
+// the last of them to finish (word 2) hands both words back as 0.
+// MEASURED (config 2, round 3) and therefore OPT-IN (MGACBAM_WSA_TAIL=1): k_bwd_reduce2 27.1 -> 22.2 us, k_bwd_apply 58.8 -> 74.3 us,
+// step 200.5 -> 207.2 us.  The 800 tile roles are ~6,900 slot-microseconds of latency-bound work wherever they run: the last resident
+// round of k_bwd_apply leaves 224 of 1024 slots free, not enough to absorb them.  (ONE last-arriving workgroup summing all partials was
+// measured first: 470 KB through one CU, +31 us.)
+__device__ __forceinline__ void bwd_wsa_tail(const BwdArgs& A, const int t, float* smem) {
+  bwd_wsa_body<7, true>(A, t, smem);
+  int* cnt = A.c.sync + static_cast<size_t>(A.g.B) * A.nflag + 1;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this workgroup's partials are out (every wave waits before the barrier)
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void bwd_wsa_sum(const BwdArgs& A, const int s, const int nsum) {
+  int* words = A.c.sync + static_cast<size_t>(A.g.B) * A.nflag;  // [0] time-out status, [1] arrivals, [2] finished sum roles
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk3 = 3 * A.g.k * A.g.k;
+  int timed_out = 0;
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    while (ld_agent(words + 1) < A.nwsa) {
+      __builtin_amdgcn_s_sleep(16);
+      if (++spins > A.spin_limit) { st_agent(words, 1); timed_out = 1; break; }
+    }
+  }
+  const bool bad = __syncthreads_or(timed_out) != 0;
+  const int o = s * (kBlock / kWave) + wave;
+  if (o < kk3) {
+    const float* part = A.s.gwsa_part + static_cast<size_t>(o) * A.nwsa;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int i = lane; i < A.nwsa; i += kWave) acc += ld_agent(part + i);
+    acc = wave_group_sum(acc, kWave);
+    if (lane == 0) A.gwsa[o] = bad ? __builtin_nanf("") : acc;   // NaN: a hand-off that timed out must be loud
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0 && __hip_atomic_fetch_add(words + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsum - 1) {
+    st_agent(words + 1, 0);                                      // every sum role has seen the full count: the next call starts from 0
+    st_agent(words + 2, 0);
+  }
+}
+
 template <typename T, int VEC, bool GMASK, bool ROLES>
 __global__ __launch_bounds__(kBlock) void k_bwd_apply(const Group<BwdArgs> G) {
   extern __shared__ __align__(16) float smem[];
@@ -818,6 +869,15 @@ __global__ __launch_bounds__(kBlock) void k_bwd_apply(const Group<BwdArgs> G) {
       return;
     }
     local -= npad;
+    if (A.wsa_tail) {
+      const int tiles = ((A.g.B + 7) / 8) * 8 * A.nt;
+      if (local >= tiles) {
+        const int nsum = (3 * A.g.k * A.g.k + 3) / 4;
+        if (local - tiles < A.nwsa) bwd_wsa_tail(A, local - tiles, smem);
+        else if (local - tiles - A.nwsa < nsum) bwd_wsa_sum(A, local - tiles - A.nwsa, nsum);
+        return;
+      }
+    }
   }
   bwd_apply_body<T, VEC, GMASK>(A, local, smem, red);
 }

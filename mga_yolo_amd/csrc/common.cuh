@@ -286,6 +286,25 @@ __device__ __forceinline__ bool handoff_wait(const int* flags, int lo, int hi, i
   return __syncthreads_or(timed_out) != 0;
 }
 
+// the same for a 2-D set of tiles: in each image row ra..rb the tiles (runs of TP pixels) that hold columns cl..ch
+__device__ __forceinline__ bool handoff_wait_rows(const int* flags, int ra, int rb, int W, int TP, int cl, int ch, int gen, int* err,
+                                                  unsigned spin_limit) {
+  int timed_out = 0;
+  const int per = (ch - cl) / TP + 2;                         // upper bound of the tiles one row's column range touches
+  for (int i = static_cast<int>(threadIdx.x); i < (rb - ra + 1) * per; i += kBlock) {
+    const int row = ra + i / per, j = i - (i / per) * per;
+    const int t = (row * W + cl) / TP + j;
+    if (t > (row * W + ch) / TP) continue;
+    unsigned spins = 0;
+    while (static_cast<int>(static_cast<unsigned>(ld_agent(flags + t)) - static_cast<unsigned>(gen)) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > spin_limit) { st_agent(err, 1); timed_out = 1; break; }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  return __syncthreads_or(timed_out) != 0;
+}
+
 // poor man's thread trace (builds with -DMGACBAM_TRACE, tools/trace_gate.py): thread 0 of a workgroup records the 100 MHz
 // wall clock at phase boundaries, slot 15 holds the hardware id (XCD / SE / CU)
 #ifdef MGACBAM_TRACE

@@ -608,13 +608,23 @@ __device__ __forceinline__ void gate_body(const FwdArgs& A, const int bid, float
   float* planes = work + ((3 * k * k + 3) & ~3);
   float* s_sa = planes + 3 * A.t.gate_rows * PW;                // gate_rows >= PH (host-computed bound)
   for (int t = tid; t < 3 * k * k; t += kBlock) wts[t] = A.p.wsa[t];
-  {
-    const int ra = max(r0 - pad, 0), rb = min(r1 + pad, g.H - 1);
+  // A tile inside ONE image row and narrower than it (wide feature maps: W = 160 at C >= 256, where a tile is 64 or 32 pixels) stages
+  // only the columns its k x k windows reach, and waits only for the tiles that hold them: 7 x 70 values per plane instead of 7 x 166,
+  // 2 tiles per row instead of all of them.  Every other tile (several rows, or a run that wraps around a row end) stages whole rows.
+  const int ra = max(r0 - pad, 0), rb = min(r1 + pad, g.H - 1);
+  const int c0 = p0 - r0 * g.W;
+  const bool narrow = r0 == r1 && (p1 - p0 + 1) + k - 1 < PW;
+  const int xa = narrow ? c0 - pad : -pad;                      // image column of the window's first column
+  const int PWs = narrow ? (p1 - p0 + 1) + k - 1 : PW;          // staged width
+  if (narrow) {
+    const int cl = max(c0 - pad, 0), ch = min(c0 + (p1 - p0) + pad, g.W - 1);
+    bad |= handoff_wait_rows(flags, ra, rb, g.W, TP, cl, ch, gen, A.c.sync + static_cast<size_t>(g.B) * A.nflag, A.spin_limit);
+  } else {
     bad |= handoff_wait(flags, (ra * g.W) / TP, ((rb + 1) * g.W - 1) / TP, gen, A.c.sync + static_cast<size_t>(g.B) * A.nflag, A.spin_limit);
   }
   TRACE_MARK(A.trace, gid, 6);                                 // neighbours' rows are there
   const float* pl = A.c.planes + static_cast<size_t>(b) * 3 * g.HW;
-  stage_window<12>(planes, 3, PH, PW, r0 - pad, -pad, g, [&](int p, int off) {
+  stage_window<12>(planes, 3, PH, PWs, r0 - pad, xa, g, [&](int p, int off) {
     const float* q = pl + static_cast<size_t>(p) * g.HW + off;
     return p < 2 ? ld_agent(q) : *q;                       // plane 2 = sigma(mask), written by k_pool (previous launch)
   });
@@ -628,7 +638,7 @@ __device__ __forceinline__ void gate_body(const FwdArgs& A, const int bid, float
     if (p0 + tp >= g.HW) break;
     const int p = p0 + tp;
     const int py = p / g.W, px = p - py * g.W;
-    const float* origin = planes + (py - r0) * PW + px;
+    const float* origin = planes + (py - r0) * PWs + (px - pad - xa);   // tap (i,j) of plane q: origin[q*PH*PWs + i*PWs + j]
     float acc = 0.f;
     if (K) {
       constexpr int KK = K ? K : 1;
@@ -636,7 +646,7 @@ __device__ __forceinline__ void gate_body(const FwdArgs& A, const int bid, float
       for (int q = 0; q < 3; ++q) {
 #pragma unroll
         for (int ti = 0; ti < KK; ++ti) {
-          const float* row = origin + q * PH * PW + ti * PW;
+          const float* row = origin + q * PH * PWs + ti * PWs;
           const float* wr = wts + (q * KK + ti) * KK;
 #pragma unroll
           for (int tj = 0; tj < KK; ++tj) acc += wr[tj] * row[tj];
@@ -645,7 +655,7 @@ __device__ __forceinline__ void gate_body(const FwdArgs& A, const int bid, float
     } else {
       for (int q = 0; q < 3; ++q)
         for (int ti = 0; ti < k; ++ti) {
-          const float* row = origin + q * PH * PW + ti * PW;
+          const float* row = origin + q * PH * PWs + ti * PWs;
           const float* wr = wts + (q * k + ti) * k;
           for (int tj = 0; tj < k; ++tj) acc += wr[tj] * row[tj];
         }
@@ -852,6 +862,7 @@ struct GateGroup {
   int nrole;                     // role workgroups = sum of the levels' batch sizes; tile workgroup ids follow
   int rstart[kGroupMax + 1];     // level l owns role ids [rstart[l], rstart[l+1])
 };
+
 
 #ifdef MGACBAM_GATE_WAVES
 #define GATE_OCC __attribute__((amdgpu_waves_per_eu(MGACBAM_GATE_WAVES)))

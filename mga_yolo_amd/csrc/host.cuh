@@ -112,6 +112,8 @@ static int env_int(const char* name, int dflt) {
 // Tuning / test knobs come from the environment ONCE (first call) -- not per call: the eager path makes ~50 look-ups per step
 // otherwise.  mgacbam_reload_env() re-reads them (tests and tuning sweeps that change the environment in-process).
 struct Knobs {
+  int wsa_tail;            // MGACBAM_WSA_TAIL (default 0, opt-in): dWsa tile partials + sums as the last workgroups of the k_bwd_apply launch
+  int gate_narrow;         // MGACBAM_GATE_NARROW (default 0): k_gate also for tiles narrower than an image row
   int gate, chan_mintx, pool_tx, pool_cpt, r2_cpt, wsa_fat, chan_tx, chanf_tx, split_mlp, nt, half_vec, gate_h8, level_order, bwd_fold;
   int resident_wgs;        // MGACBAM_RESIDENT_WGS: override of the co-resident workgroup budget the hand-off eligibility is sized from
   int fault;               // MGACBAM_FAULT: fault injection for tests (args.cuh)
@@ -120,6 +122,8 @@ struct Knobs {
 };
 static Knobs read_knobs() {
   Knobs k;
+  k.wsa_tail = env_int("MGACBAM_WSA_TAIL", 0);
+  k.gate_narrow = env_int("MGACBAM_GATE_NARROW", 0);
   k.gate = env_int("MGACBAM_GATE", 1); k.chan_mintx = env_int("MGACBAM_CHAN_MINTX", 16);
   k.pool_tx = env_int("MGACBAM_POOL_TX", 0); k.pool_cpt = env_int("MGACBAM_POOL_CPT", 0); k.chan_tx = env_int("MGACBAM_CHAN_TX", 0);
   k.nt = env_int("MGACBAM_NT", 1); k.half_vec = env_int("MGACBAM_HALF_VEC", 4); k.gate_h8 = env_int("MGACBAM_GATE_H8", 1);
@@ -206,10 +210,14 @@ static void gate_geometry(int C, int H, int W, int k, int VEC, Tune& t) {
   grows += k - 1;
   const int span = ((k / 2) * W + TP - 1) / TP + 1;           // tiles reached on either side
   const size_t lds = (3 * static_cast<size_t>(grows) * (W + k - 1) + TP + 3 * k * k + 3 * C + 64) * sizeof(float);
-  // TP >= W: a tile narrower than an image row stages k+1 full rows for a fraction of a row of outputs (measured at
-  // 1280-px inputs, C = 256/512: k_gate 220 us against 207 us for k_chan + k_apply; at >= 1.6 rows per tile it wins 18-20 %)
+  // TP < W (wide feature maps at C >= 256: a tile is a fraction of an image row).  Supported -- a tile inside one row stages and waits
+  // for only the columns its windows reach (fwd.cuh: `narrow`), parity-tested -- but OPT-IN (MGACBAM_GATE_NARROW=1): at BASELINE
+  // configs[3] it measures 224 us against 201 us for k_mlp + k_chan + k_apply.  tools/trace_gate.py fwd cfg4: a 64- / 32-pixel tile
+  // needs rows of up to 3 below it, i.e. tiles 7-8 positions AHEAD in dispatch order, and sits 6.8 us (p90 11) waiting for them to be
+  // scheduled and to reach their publish point; the TY = 16 / 32 channel slices combine through LDS in 5.2 us; the C = 512 role MLP
+  // takes 20 us for the first round; 60 % of the resident workgroups are in the chain at any time and HBM runs at 3 TB/s
   // (whether the 8*span + 1 workgroups a tile's wait spans are co-resident on THIS device is checked at dispatch: forward_group)
-  if (TP >= kSyncPx && TP >= W && lds <= 48 * 1024) { t.gate_tx = gtx; t.gate_rows = grows; t.gate_span = span; }
+  if (TP >= kSyncPx && (TP >= W || knobs().gate_narrow) && lds <= 48 * 1024) { t.gate_tx = gtx; t.gate_rows = grows; t.gate_span = span; }
 }
 
 static Tune choose_tune(int B, int C, int H, int W, int k, int dtype = MGACBAM_F32) {

@@ -352,14 +352,28 @@ def test_plan_executor_matches_oracle_with_and_without_projection_planes(F, want
     ([(32, 128, 80, 80), (32, 256, 40, 40), (32, 512, 20, 20)], True, True), # BASELINE configs[2] per GPU: twice the workgroups, several resident rounds
     ([(3, 48, 17, 17), (5, 24, 9, 7)], True, True),                        # scalar (VEC=1) path, ragged, different B per level
     ([(9, 64, 40, 40), (9, 64, 20, 20)], False, True),                     # no mask; B not a multiple of the 8 XCDs
-    ([(2, 256, 6, 160), (2, 64, 12, 80)], True, False),                    # a tile narrower than a row (64 px < W = 160): the group falls back
+    ([(2, 256, 6, 160), (2, 64, 12, 80)], True, True),                     # a tile narrower than a row (64 px < W = 160): column-windowed staging
+    ([(2, 256, 16, 160), (2, 512, 12, 80), (3, 512, 8, 40)], True, True),  # BASELINE configs[3] widths: 64- / 32-px tiles in 160- / 80- / 40-px rows (runs that wrap)
+    ([(8, 256, 160, 160)], True, True),                                    # configs[3] P3 at full size: 3,200 narrow tiles, several resident rounds
+    ([(1, 192, 9, 200), (2, 96, 5, 37)], False, True),                     # no mask; W not a multiple of the tile; scalar path
 ])
-def test_fused_forward_launch_equals_three_launches(F, shapes, with_mask, fused):
+def test_fused_forward_launch_equals_three_launches(F, shapes, with_mask, fused, monkeypatch):
     """MGACBAM_FWD_FUSE: k_chan + k_apply as ONE x-resident launch (k_gate) with in-launch hand-off of the plane rows.
     Outputs and saved ctx fields must match the three-launch forward (same arithmetic per element; only the order of the
     channel-mean sum differs), the time-out word must stay clear and every tile flag must read the call count -- the
     next call depends on it -- also under graph replay."""
+    from mga_yolo_amd import _lib
     from mga_yolo_amd.plan import PyramidPlan
+    monkeypatch.setenv("MGACBAM_GATE_NARROW", "1")          # tiles narrower than an image row take k_gate too (opt-in: slower than the fallback)
+    _lib.reload_env()
+    try:
+        _fused_vs_three(F, PyramidPlan, shapes, with_mask, fused)
+    finally:
+        monkeypatch.undo()
+        _lib.reload_env()
+
+
+def _fused_vs_three(F, PyramidPlan, shapes, with_mask, fused):
     params, cfgs = [], []
     for l, (B, C, H, W) in enumerate(shapes):
         p = O.Params.default_init(C, seed=l)
@@ -807,3 +821,42 @@ def test_half_precision_mask_gets_its_gradient_in_its_own_dtype(F, mdtype, tol):
     from mga_yolo_amd.module import _eca_host_forward
     _eca_host_forward(xh, mh, we, be, EcaConfig(k=3)).backward(gy)
     assert md.grad.dtype == mdtype and rel_err(md.grad.float(), mh.grad) < tol and rel_err(xd.grad, xh.grad) < TOL
+
+
+def test_dwsa_tail_roles_give_the_same_bits(F, monkeypatch):
+    """MGACBAM_WSA_TAIL=1 (opt-in): the dWsa tile partials and their fixed-order sums ride at the END of the k_bwd_apply launch behind an
+    arrival counter instead of at the front of k_bwd_reduce2 -- every gradient must equal the default placement bit for bit, over
+    repeated calls and graph replays (the counters return to 0 each call), and the hand-off status must stay clear."""
+    from mga_yolo_amd import _lib
+    from mga_yolo_amd.plan import PyramidPlan
+    shapes = [(8, 64, 40, 40), (8, 128, 20, 20), (5, 256, 10, 10)]
+    params, cfgs, data = [], [], []
+    for l, (B, C, H, W) in enumerate(shapes):
+        p = O.Params.default_init(C, seed=l)
+        p.beta.fill_(0.2)
+        params.append((p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta))
+        cfgs.append(F.BlockConfig(hidden=p.w1.shape[0]))
+        data.append(synth(B, C, H, W, seed=60 + l, mask_kind="mixed"))
+
+    def run():
+        plan = PyramidPlan(shapes, params, cfgs)
+        for l, (x, mask, gy) in enumerate(data):
+            plan.x[l].copy_(x); plan.mask[l].copy_(mask); plan.gy[l].copy_(gy)
+        for _ in range(3):
+            plan.forward(); plan.backward()
+        g = plan.capture(lambda: (plan.forward(), plan.backward()))
+        g.replay(); g.replay()
+        plan.check_handoff()
+        words = [plan.ctx_view(l)["sync"][B * ((H * W + 15) // 16 + 1):][:4].clone() for l, (B, C, H, W) in enumerate(shapes)]
+        return plan.grad_bucket.clone(), [t.clone() for t in plan.gx], words
+
+    base = run()
+    monkeypatch.setenv("MGACBAM_WSA_TAIL", "1")
+    _lib.reload_env()
+    try:
+        tail = run()
+    finally:
+        monkeypatch.undo()
+        _lib.reload_env()
+    assert torch.equal(base[0], tail[0]) and all(torch.equal(a, b) for a, b in zip(base[1], tail[1]))
+    assert all(int(w.abs().sum()) == 0 for w in tail[2]), "arrival counters must be back at 0 between calls"

@@ -1,6 +1,6 @@
 """Poor man's thread trace of k_gate (needs a -DMGACBAM_TRACE build: python -c "from mga_yolo_amd import build;
-build.build(force=True, defines=['-DMGACBAM_TRACE'], out='mga_yolo_amd/libmgacbam_trace.so')", then run with
-MGACBAM_LIB=$PWD/mga_yolo_amd/libmgacbam_trace.so).  Thread 0 of every workgroup records the 100 MHz wall clock at phase
+build.build(defines=['-DMGACBAM_TRACE'], out='build/variants/libmgacbam_trace.so')", then run with
+MGACBAM_LIB=$PWD/build/variants/libmgacbam_trace.so).  Thread 0 of every workgroup records the 100 MHz wall clock at phase
 boundaries; this prints, per phase, when workgroups reach it (percentiles over workgroups, us since the first start) and the
 per-CU residency."""
 import os
@@ -19,8 +19,8 @@ NAMES_POOL = ["start", "-", "-", "sweep done", "-", "-", "-", "-", "reduced", "-
 
 
 def main():
-    plan, desc, batch = bench.make_plan("cfg2", torch.device("cuda", 0), seed=1, dtype_name="f32")
-    nblk = 4096
+    plan, desc, batch = bench.make_plan(sys.argv[2] if len(sys.argv) > 2 else "cfg2", torch.device("cuda", 0), seed=1, dtype_name="f32")
+    nblk = 16384
     buf = torch.zeros(nblk * 16, dtype=torch.int64, device="cuda")
     which = sys.argv[1] if len(sys.argv) > 1 else "fwd"       # fwd: k_gate, bwd: k_bwd_apply
     NAMES = {"fwd": NAMES_FWD, "bwd": NAMES_BWD, "pool": NAMES_POOL}[which]
@@ -81,6 +81,19 @@ def main():
     key = xcc * 1000 + se_id * 16 + cu_id
     uniq, cnt = np.unique(key, return_counts=True)
     print(f"{len(uniq)} distinct (xcc,se,cu); workgroups per CU: min {cnt.min()} median {np.median(cnt)} max {cnt.max()}")
+    # hardware slot ids of the workgroups that start in the first 2 us (the first resident round): is there one of each per CU?
+    first = us(tiles[:, 0]) < 2.0
+    wave_id, simd_id, tg_id = cu & 0xF, (cu >> 4) & 0x3, (cu >> 16) & 0xF
+    for name, v in (("wave_id", wave_id), ("simd_id", simd_id), ("tg_id", tg_id)):
+        vals, c = np.unique(v[first], return_counts=True)
+        print(f"first-round {name}: " + " ".join(f"{a}:{b}" for a, b in zip(vals, c)))
+    per_cu = {}
+    for k_, w_, t_ in zip(key[first], wave_id[first], tg_id[first]):
+        per_cu.setdefault(k_, []).append((int(w_), int(t_)))
+    combos = {}
+    for v in per_cu.values():
+        combos[tuple(sorted(v))] = combos.get(tuple(sorted(v)), 0) + 1
+    print("first-round (wave_id, tg_id) sets per CU:", sorted(combos.items(), key=lambda kv: -kv[1])[:8])
     # concurrency over time: how many tile workgroups are in [start, stores done) at each us
     life = np.stack([us(tiles[:, 0]), us(tiles[:, 10])], 1)
     for tt in range(0, int(life[:, 1].max()) + 1, 4):
