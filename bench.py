@@ -47,6 +47,10 @@ WORKLOADS = {
              [(256, 160, 160), (512, 80, 80), (512, 40, 40)]),
 }
 
+# whole-model fp32 gradient payload per step of the model each workload stands for (parameters x 4 B), and its scale letter
+MODEL_GRAD_MB = {"cfg2": 11.9, "cfg1": 11.9, "p3": 11.9, "p4": 11.9, "p5": 11.9, "cfg3": 43.7, "cfg4": 93.7}
+MODEL_SCALE = {"cfg3": "s", "cfg4": "m"}
+
 # algorithmic bytes of each HBM-bound kernel in units of E*w (feature-sized tensors it must read or write once)
 FWD_KERNEL_E = {"pool": 1, "chan": 1, "apply": 2, "gate": 2}   # k_gate = chan + apply with x resident: read x once, write y
 BWD_KERNEL_E = {"reduce1": 2, "reduce2": 1, "apply": 3}
@@ -69,6 +73,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the bounded CPU-baseline sample (>= 50 iterations at config 2 need ~15 s)")
     ap.add_argument("--kernel-reps", type=int, default=30)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "bf16"], help="element type of x / y / gy / gx (headline = f32)")
+    ap.add_argument("--grad-payload-mb", type=float, default=None,
+                    help="N > 1: fp32 gradient bytes of the layers OUTSIDE the hot path that ride in the same all-reduce every step, in 25 MB "
+                         "buckets as DDP cuts them (default: the workload's whole-model figure, SURVEY 2: n 11.9, s 43.7, m 93.7; 0 = the blocks' own bucket only)")
+    ap.add_argument("--no-harness", action="store_true", help="skip the train-step harness (tools/harness.py, extra key train_harness)")
+    ap.add_argument("--harness-steps", type=int, default=8)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for rehearsing the multi-rank code path on one GPU)")
     return ap.parse_args()
 
@@ -341,7 +350,12 @@ def main():
         os.environ["MGACBAM_FUSE_FWD"] = "0"
         os.environ["MGACBAM_FOLD_BWD"] = "0"
     plan, desc, batch = make_plan(args.workload, device, seed=1234 + rank, dtype_name=args.dtype)
-    exchange = GradExchange(plan.grad_bucket)                    # no-op when world == 1
+    # N > 1: what DDP puts through the collective every step is the WHOLE model's gradient (U/engine/trainer.py:366-367), of which the
+    # blocks' own bucket is 47 KB: the rest rides along as payload buckets, so that the exchange the step has to hide is the real one
+    from mga_yolo_amd.dp import payload_buckets
+    payload_mb = MODEL_GRAD_MB.get(args.workload, 0.0) if args.grad_payload_mb is None else args.grad_payload_mb
+    payload = payload_buckets(int(payload_mb * 1e6) if world > 1 else 0, device)
+    exchange = GradExchange([plan.grad_bucket] + payload)        # no-op when world == 1
 
     S = _lib.FWD_STAGES
 
@@ -459,6 +473,16 @@ def main():
     slice_res = None
     if rank == 0 and world == 1 and not args.no_eager and args.dtype == "f32":
         slice_res = slice_step(args.workload, device)
+    # SURVEY 8d images/s definition (2): the train-step harness, under DDP when N > 1 (every rank takes part)
+    harness_res = None
+    if not args.no_harness and not args.no_eager:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import harness
+            harness_res = harness.run(MODEL_SCALE.get(args.workload, "n"), batch=batch, size=1280 if args.workload == "cfg4" else 640,
+                                      steps=args.harness_steps, warmup=3, device=device, world=world, rank=rank)
+        except Exception as e:                                    # the harness is an extra key: its failure must not cost the headline line
+            harness_res = dict(error=f"{type(e).__name__}: {e}"[:300])
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, args.cpu_seconds)
@@ -470,10 +494,15 @@ def main():
                     config=dict(workload=desc, batch_per_gpu=batch, global_batch=batch * world,
                                 levels=[list(s) for s in plan.shapes], parallelism=f"dp{world}", backend=(args.backend if world > 1 else None),
                                 launch="eager" if args.no_graph else ((f"hipGraph replay, {max(1, args.steps_per_graph)} step(s)/graph" if args.steps_per_graph > 1 else "hipGraph replay, 1 graph/step") if world == 1 else "hipGraph replay, 2 graphs/step (split at the gradient-exchange join)"),
-                                grad_exchange=None if world == 1 else f"{'RCCL' if args.backend == 'nccl' else args.backend} all-reduce of one {plan.grad_bucket.numel() * 4} B bucket per step, overlapped with the next step's parameter-free k_pool",
+                                grad_exchange=None if world == 1 else dict(
+                                    collective=f"{'RCCL' if args.backend == 'nccl' else args.backend} all-reduce(mean), one side stream, buckets in order",
+                                    block_bucket_bytes=plan.grad_bucket.numel() * 4, payload_mb=payload_mb, payload_buckets=[b.numel() * 4 for b in payload],
+                                    total_bytes=exchange.nbytes(),
+                                    placement="started after the backward that produces the gradients, overlapped with the next step's parameter-free k_pool, joined before the first kernel that reads a parameter (the DDP contract); the payload stands for the out-of-scope layers' gradients, whose own backward -- absent here -- is what hides most of it in a whole-model step (see train_harness)"),
                                 handoff_kernels=bool(plan.fuse_forward)),
                     roofline=roofline, step_roofline=step_roof, kernels=kernels, cpu_baseline=cpu,
                     eager_module_ms_per_step=eager_ms, eager_module_ms_per_step_engine_inline=eager_inline_ms, layer_loop_slice=slice_res,
+                    train_harness=harness_res,
                     eager_module_note="the unchanged reference layer loop's path: three MaskCBAM modules through autograd, one library call per level each way, launches issued from Python (no PyramidPlan / hipGraph), gradients reset to None every step as the trainer does; engine_inline = autograd engine on the calling thread (the blocks' marginal cost inside a whole-model backward, which pays the engine's worker-thread wake-up once for all layers)",
                     lib=_lib.load().mgacbam_build_info().decode())
         print(json.dumps(line))

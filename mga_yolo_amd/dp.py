@@ -27,20 +27,34 @@ def shard_batch(global_batch: int, world_size: int, rank: int) -> slice:
     return slice(rank * per, (rank + 1) * per)
 
 
-class GradExchange:
-    """All-reduce(mean) of one flat gradient bucket, overlapped with whatever the caller enqueues between
-    ``start()`` and ``finish()``."""
+def payload_buckets(nbytes: int, device, cap_mb: float = 25.0):
+    """fp32 buffers standing for the gradients of the layers OUTSIDE the hot path (backbone / neck / Detect: 11.9 MB for YOLOv8n ...
+    130 MB for l), cut the way DistributedDataParallel cuts them: buckets of `cap_mb` (its default bucket_cap_mb = 25)."""
+    n = max(0, int(nbytes) // 4)
+    cap = max(1, int(cap_mb * (1 << 20)) // 4)
+    return [torch.zeros(min(cap, n - o), dtype=torch.float32, device=device) for o in range(0, n, cap)]
 
-    def __init__(self, bucket: torch.Tensor, group: Optional[dist.ProcessGroup] = None):
-        self.bucket = bucket
+
+class GradExchange:
+    """All-reduce(mean) of flat gradient buckets, overlapped with whatever the caller enqueues between ``start()`` and
+    ``finish()``.  One bucket (the blocks' own parameter gradients) or several (plus ``payload_buckets``: the rest of the model's
+    gradients, which DDP puts through the same collective every step, U/engine/trainer.py:366-367): the buckets are reduced one
+    after the other on ONE side stream, in order -- what DDP's reducer does with its ready buckets."""
+
+    def __init__(self, bucket, group: Optional[dist.ProcessGroup] = None):
+        self.buckets = list(bucket) if isinstance(bucket, (list, tuple)) else [bucket]
+        self.bucket = self.buckets[0]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.on_gpu = bucket.is_cuda
-        self.side = torch.cuda.Stream(bucket.device) if self.on_gpu else None
+        self.on_gpu = self.bucket.is_cuda
+        self.side = torch.cuda.Stream(self.bucket.device) if self.on_gpu else None
         self._ready = torch.cuda.Event() if self.on_gpu else None
         self._work = None
         # RCCL averages inside the collective (one kernel fewer on the side stream than SUM + div_); gloo has no AVG
         self.avg_in_collective = bool(self.on_gpu and self.world > 1 and dist.get_backend(group) == "nccl")
+
+    def nbytes(self) -> int:
+        return sum(b.numel() * b.element_size() for b in self.buckets)
 
     def start(self):
         if self.world == 1:
@@ -51,20 +65,24 @@ class GradExchange:
             self.side.wait_event(self._ready)
             op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
             with torch.cuda.stream(self.side):
-                self._work = dist.all_reduce(self.bucket, op=op, group=self.group, async_op=True)
+                self._work = [dist.all_reduce(b, op=op, group=self.group, async_op=True) for b in self.buckets]
         else:
-            self._work = dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._work = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
 
     def finish(self):
         if self.world == 1 or self._work is None:
             return
         if self.on_gpu:
             with torch.cuda.stream(self.side):
-                self._work.wait()                         # orders the side stream after the collective
+                for w in self._work:
+                    w.wait()                              # orders the side stream after the collective
                 if not self.avg_in_collective:
-                    self.bucket.div_(self.world)          # DDP semantics: mean over replicas
+                    for b in self.buckets:
+                        b.div_(self.world)                # DDP semantics: mean over replicas
             torch.cuda.current_stream(self.bucket.device).wait_stream(self.side)
         else:
-            self._work.wait()
-            self.bucket.div_(self.world)
+            for w in self._work:
+                w.wait()
+            for b in self.buckets:
+                b.div_(self.world)
         self._work = None

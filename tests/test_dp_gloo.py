@@ -138,3 +138,61 @@ def test_exchange_is_a_no_op_without_a_process_group():
     ex = GradExchange(b)
     ex.start(); ex.finish()
     assert ex.world == 1 and torch.equal(b, torch.arange(6, dtype=torch.float32))
+
+
+def _harness_worker(rank, world, port, q):
+    """SURVEY 8d images/s definition (2): the train-step harness (tools/harness.py: backbone stand-in -> MGAMaskHead -> MaskCBAM ->
+    SegmentationLoss -> Kendall combine, the loss formed inside forward) inside the reference's wrapper,
+    DistributedDataParallel(find_unused_parameters=True) (U/engine/trainer.py:366-367), two gloo ranks on the host."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import harness
+    dev = torch.device("cpu")
+    model, wrapped, opt = harness.build("n", dev, world, depth=1)
+    img, masks = harness.synthetic_batch(2, 64, dev, seed=100 + rank)
+    opt.zero_grad(set_to_none=True)
+    loss = wrapped(img, masks)
+    loss.backward()
+    grads = {n: p.grad.numpy().copy() for n, p in model.named_parameters()}
+    res = harness.run("n", batch=2, size=64, steps=2, warmup=1, device=dev, world=world, rank=rank)     # the timed loop runs under DDP too
+    q.put((rank, float(loss), grads, res["images_per_s"], res["ddp"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_train_harness_inside_ddp_matches_the_mean_of_the_shards():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import harness
+    world = 2
+    ctx_mp = mp.get_context("spawn")
+    q = ctx_mp.Queue()
+    port = 29700 + (os.getpid() % 90)
+    procs = [ctx_mp.Process(target=_harness_worker, args=(r, world, port, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    got = {r: (l, g, ips, ddp) for r, l, g, ips, ddp in (q.get(timeout=500) for _ in range(world))}
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    # single process: the same model on each shard in turn, gradients averaged by hand
+    dev = torch.device("cpu")
+    want = None
+    for r in range(world):
+        model, wrapped, opt = harness.build("n", dev, 1, depth=1)
+        img, masks = harness.synthetic_batch(2, 64, dev, seed=100 + r)
+        loss = wrapped(img, masks)
+        assert abs(float(loss) - got[r][0]) <= 1e-5 * abs(float(loss))
+        loss.backward()
+        g = {n: p.grad.clone() / world for n, p in model.named_parameters()}
+        want = g if want is None else {n: want[n] + g[n] for n in g}
+    names = set(want)
+    assert any(n.startswith("blocks.") for n in names) and any(n.startswith("heads.") for n in names) and "mtl_log_vars" in names
+    for n, w in want.items():
+        for r in range(world):
+            assert abs(got[r][1][n] - w.numpy()).max() <= 2e-5 * max(float(w.abs().max()), 1e-8), (n, r)
+        assert (got[0][1][n] == got[1][1][n]).all(), n
+    assert all(got[r][2] > 0 and got[r][3] for r in range(world))
