@@ -211,7 +211,7 @@ def eager_module_step(workload, device, dtype_name, steps=60, warmup=10, engine_
         torch.autograd.set_multithreading_enabled(prev)
 
 
-def slice_step(workload, device, steps=100, warmup=10):
+def slice_step(workload, device, steps=100, warmup=10, dtype_name="f32"):
     """SURVEY 8d images/s definition (2), in scope: the LAYER-LOOP SLICE of the training step (mga_yolo_amd/slice.py) -- three mask heads,
     three MaskCBAM blocks, the multi-scale segmentation loss, the Kendall combine and the backward of all of it, replayed from one
     hipGraph.  Backbone / neck / Detect / detection loss are out of scope: they enter as given tensors (dL/d refined, det_loss)."""
@@ -226,7 +226,8 @@ def slice_step(workload, device, steps=100, warmup=10):
         hid = max(8, ((C // 4) + 7) // 8 * 8)                    # yolov8_cbam.yaml: MGAMaskHead [C*4, C] width-scaled -> hidden = C / 4
         h = MGAMaskHead(C, hid)
         shapes.append((batch, C, H, W)); hidden.append(hid); cps.append(m.block_params()); cfgs.append(m.block_config()); hss.append(h.state_dict())
-    plan = SlicePlan(shapes, hidden, cps, cfgs, hss, device=device)
+    dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dtype_name]
+    plan = SlicePlan(shapes, hidden, cps, cfgs, hss, device=device, dtype=dt)
     g = torch.Generator(device="cpu").manual_seed(7)
     for l, (B, C, H, W) in enumerate(shapes):
         plan.x[l].copy_(torch.nn.functional.silu(torch.randn(B, C, H, W, generator=g)))
@@ -471,8 +472,8 @@ def main():
         from mga_yolo_amd import handoff_report
         handoff_report()
     slice_res = None
-    if rank == 0 and world == 1 and not args.no_eager and args.dtype == "f32":
-        slice_res = slice_step(args.workload, device)
+    if rank == 0 and world == 1 and not args.no_eager:
+        slice_res = slice_step(args.workload, device, dtype_name=args.dtype)
     # SURVEY 8d images/s definition (2): the train-step harness, under DDP when N > 1 (every rank takes part)
     harness_res = None
     if not args.no_harness and not args.no_eager:

@@ -316,17 +316,18 @@ typedef struct mgahead_params {
 
 typedef struct mgahead_fwd_level {
   const void* x;               /* (B,C,H,W) feature of `dtype`                                 */
-  void* logits;                /* (B,1,H,W) mask logits of `dtype`                             */
+  void* logits;                /* (B,1,H,W) mask logits of `dtype` (fp32 with MGAHEAD_LOGITS_F32) */
   void* ctx;                   /* mgahead_ctx_bytes(): z, batch statistics (kept for backward) */
   size_t ctx_bytes;            /* capacity of ctx (checked: MGACBAM_E_SIZE)                    */
   mgahead_params_t p;
   int32_t B, C, H, W;
   int32_t dtype;
+  int32_t flags;               /* MGAHEAD_LOGITS_F32                                           */
 } mgahead_fwd_level_t;
 
 typedef struct mgahead_bwd_level {
   const void* x;               /* as in forward                                                */
-  const void* g_logits;        /* (B,1,H,W) dL/dlogits of `dtype`                              */
+  const void* g_logits;        /* (B,1,H,W) dL/dlogits of `dtype` (fp32 with MGAHEAD_LOGITS_F32) */
   const float* g_logits2;      /* optional second addend of dL/dlogits, fp32 (B,1,H,W), or NULL: the logits feed the segmentation loss AND
                                   MaskCBAM (model.py:57-64, 196-202); passing MaskCBAM's dL/dmask here saves the add launch */
   const void* ctx;             /* written by the matching forward                              */
@@ -346,7 +347,11 @@ typedef struct mgahead_bwd_level {
                                   feature feeds both its mask head and its MaskCBAM, model.py:57-64) and this call ADDS to it in the GEMM
                                   epilogue -- the feature-sized add autograd would do as a pass of its own disappears            */
 } mgahead_bwd_level_t;
-enum { MGAHEAD_BWD_ACCUM_GX = 1 };
+enum {
+  MGAHEAD_BWD_ACCUM_GX = 1,
+  MGAHEAD_LOGITS_F32 = 2       /* forward: logits, backward: g_logits are fp32 whatever `dtype` is -- half-precision features with the mask
+                                  logits handed to MaskCBAM (whose mask input is fp32) and to the loss without a conversion pass        */
+};
 
 size_t mgahead_ctx_bytes(int B, int C, int H, int W, int hidden);
 size_t mgahead_bwd_scratch_bytes(int B, int C, int H, int W, int hidden);

@@ -94,7 +94,7 @@ class HeadParams(C.Structure):                   # mgahead_params_t
 
 class HeadFwdLevel(C.Structure):                 # mgahead_fwd_level_t
     _fields_ = [("x", C.c_void_p), ("logits", C.c_void_p), ("ctx", C.c_void_p), ("ctx_bytes", C.c_size_t), ("p", HeadParams),
-                ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dtype", C.c_int32)]
+                ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dtype", C.c_int32), ("flags", C.c_int32)]
 
 
 class HeadBwdLevel(C.Structure):                 # mgahead_bwd_level_t
@@ -105,7 +105,7 @@ class HeadBwdLevel(C.Structure):                 # mgahead_bwd_level_t
                 ("flags", C.c_int32)]
 
 
-HEAD_BWD_ACCUM_GX = 1
+HEAD_BWD_ACCUM_GX, HEAD_LOGITS_F32 = 1, 2
 
 
 class PmgCfg(C.Structure):                       # mgapmg_cfg_t

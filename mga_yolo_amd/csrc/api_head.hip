@@ -179,7 +179,7 @@ static int head_forward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t s
     const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.nwg_out; });
     const size_t smem = std::max(static_cast<size_t>(4) * ohl, static_cast<size_t>(16) * kWave) * sizeof(float);
 #define CALL_HO(Tt) { if (sig.vec == 4) { LAUNCH((k_head_out<Tt, 4>), grid, smem, st, G); } else { LAUNCH((k_head_out<Tt, 1>), grid, smem, st, G); } }
-    switch (sig.dtype) {
+    switch (sig.lf32 ? MGACBAM_F32 : sig.dtype) {              // (the kernel's element type is the LOGITS' type: z is fp32)
       case MGACBAM_F32: CALL_HO(float); break;
       case MGACBAM_F16: CALL_HO(__half); break;
       default: CALL_HO(bf16_t); break;
@@ -202,6 +202,7 @@ extern "C" int mgahead_forward(const mgahead_fwd_level_t* levels, int n_levels, 
     const size_t need = sigs[l].vec * elem_size(L.dtype);
     if (!aligned_to(L.x, need) || !aligned_to(L.ctx, 16)) return fail(MGACBAM_E_ALIGN, "mask head forward: x must be %zu-byte aligned, ctx 16-byte", need);
     args[l].x = L.x; args[l].logits = L.logits;
+    sigs[l].lf32 = (L.flags & MGAHEAD_LOGITS_F32) ? 1 : 0;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (int e = for_each_group(args, sigs, n_levels, [&](HeadArgs* g, int m, const Sig& s) { return head_forward_group(g, m, s, st); })) return e;
@@ -218,7 +219,7 @@ static int head_backward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t 
     for (int l = 0; l < n; ++l) { lv[l].act_hl_max = hl; G.lv[l].act_hl_max = hl; }      // the reduction scratch sits behind the launch's longest run
     const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.nwg1 * ((a.g.hid + kHeadJC - 1) / kHeadJC); });
     const size_t smem = (static_cast<size_t>(hl) + 16 * kHeadJC * kHeadNStat) * sizeof(float);
-    switch (sig.dtype) {
+    switch (sig.lf32 ? MGACBAM_F32 : sig.dtype) {              // (the kernel's element type is g_logits' type)
       case MGACBAM_F32: LAUNCH(k_head_bwd_act<float>, grid, smem, st, G); break;
       case MGACBAM_F16: LAUNCH(k_head_bwd_act<__half>, grid, smem, st, G); break;
       default: LAUNCH(k_head_bwd_act<bf16_t>, grid, smem, st, G); break;
@@ -296,6 +297,7 @@ extern "C" int mgahead_backward(const mgahead_bwd_level_t* levels, int n_levels,
     A.x = L.x; A.gl = L.g_logits; A.gx = L.gx;
     A.gw1 = L.gw1; A.ggamma = L.gbn_weight; A.gbeta = L.gbn_bias; A.gwh = L.gwh; A.gbh = L.gbh;
     A.accum_gx = (L.flags & MGAHEAD_BWD_ACCUM_GX) ? 1 : 0;
+    sigs[l].lf32 = (L.flags & MGAHEAD_LOGITS_F32) ? 1 : 0;
     A.gl2 = L.g_logits2;
     const HeadScratchLayout SL = head_scratch_layout(L.B, L.C, L.H, L.W, L.p.hidden);
     if (int e = check_capacity("mask head backward", "ctx", head_ctx_layout(L.B, L.C, L.H, L.W, L.p.hidden).total, L.ctx_bytes)) return e;

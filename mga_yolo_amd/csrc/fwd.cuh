@@ -567,16 +567,34 @@ __device__ __forceinline__ void gate_body(const FwdArgs& A, const int bid, float
   }
   TRACE_MARK(A.trace, gid, 3);                                 // x arrived, per-thread channel scan done
   {
+    // The TY channel slices of a pixel vector meet in two steps.  (1) Inside a wave: with TX < 64 a wave holds 64 / TX slices of the same
+    // TX vectors, TX lanes apart -- xor butterflies over the lane offsets TX .. 32 leave every lane with the wave's combined triple.
+    // (2) Across the waves through LDS: one partial per wave and vector, combined by the ty == 0 lanes.  (Round 2 sent all TY slices
+    // through LDS and let TX lanes walk them one after the other: with TY = 16 / 32 -- C = 256 / 512 -- that loop was 5.2 us of a 31 us
+    // workgroup, tools/trace_gate.py fwd cfg4.)
+    for (int off = TX; off < kWave; off <<= 1) {                 // (uniform)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float ov = __shfl_xor(vmax[e], off);
+        const int oi = __shfl_xor(vidx[e], off);
+        argmax_combine(vmax[e], vidx[e], ov, oi);
+        vsum[e] += __shfl_xor(vsum[e], off);
+      }
+    }
+    const int spw = TX < kWave ? kWave / TX : 1;                 // slices per wave
+    const int ngrp = TY / spw;                                   // partials per vector left to combine (4 whenever TX <= 64)
+    const int grp = ty / spw;
     float* smax = work;
     int* sidx = reinterpret_cast<int*>(work + kBlock * VEC);
     float* ssum = work + 2 * kBlock * VEC;
-    if (ty > 0) {
+    if (grp > 0 && ty == grp * spw) {
+      const int o = (grp * TX + tx) * VEC;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) { smax[tid * VEC + e] = vmax[e]; sidx[tid * VEC + e] = vidx[e]; ssum[tid * VEC + e] = vsum[e]; }
+      for (int e = 0; e < VEC; ++e) { smax[o + e] = vmax[e]; sidx[o + e] = vidx[e]; ssum[o + e] = vsum[e]; }
     }
     __syncthreads();
     if (ty == 0 && active) {
-      for (int r = 1; r < TY; ++r) {
+      for (int r = 1; r < ngrp; ++r) {
         const int o = (r * TX + tx) * VEC;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {

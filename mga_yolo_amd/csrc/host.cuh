@@ -349,11 +349,12 @@ static int check_params(const mgacbam_params_t& p) {
 // conv size, dL/dmask wanted) are launched together: one grid per stage, the levels' grids concatenated.
 struct Sig {
   int dtype, vec, has_mask, k, gmask, proj;
+  int lf32 = 0;   // mask head only: logits / g_logits are fp32 whatever dtype is (MGAHEAD_LOGITS_F32)
   int gvec = 0;   // forward only: elements per lane of k_gate for this level -- a function of the LEVEL alone (dtype, shape, k, knobs), never of
                   // the levels it happens to be called with: the hand-off flags in ctx.sync count calls per TILE, so a ctx must see the same
                   // tiling in every call whatever the group composition (levels of different gvec go to different launches)
   bool operator==(const Sig& o) const {
-    return dtype == o.dtype && vec == o.vec && has_mask == o.has_mask && k == o.k && gmask == o.gmask && proj == o.proj && gvec == o.gvec;
+    return dtype == o.dtype && vec == o.vec && has_mask == o.has_mask && k == o.k && gmask == o.gmask && proj == o.proj && gvec == o.gvec && lf32 == o.lf32;
   }
 };
 

@@ -572,7 +572,7 @@ class _HeadFn(torch.autograd.Function):
             L = levels[l]
             L.x, L.logits, L.ctx, L.ctx_bytes = xc.data_ptr(), logits.data_ptr(), cbuf.data_ptr(), cbuf.numel()
             L.p = _head_params(*pc[:3], rmean, rvar, nbt, *pc[3:], hid, float(eps), float(momentum), training)
-            L.B, L.C, L.H, L.W, L.dtype = B, Cc, H, W, _DTYPES[x.dtype]
+            L.B, L.C, L.H, L.W, L.dtype, L.flags = B, Cc, H, W, _DTYPES[x.dtype], 0
             keep += [xc, cbuf, *pc, rmean, rvar]
             outs.append(logits)
             meta.append((hid, float(eps), float(momentum), bool(training), tuple(w1.shape)))

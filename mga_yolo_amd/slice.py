@@ -31,10 +31,13 @@ HEAD_PARAM_NAMES = ("proj.0.weight", "proj.1.weight", "proj.1.bias", "head.weigh
 class SlicePlan:
     def __init__(self, shapes: Sequence[Tuple[int, int, int, int]], hidden: Sequence[int], cbam_params, cbam_cfgs: Sequence[BlockConfig],
                  head_states: Sequence[dict], target_hw: Sequence[Tuple[int, int]] = None, scale_weights=(1.0, 1.0, 1.0),
-                 bn_eps: float = 1e-3, bn_momentum: float = 0.03, device="cuda", training: bool = True):
+                 bn_eps: float = 1e-3, bn_momentum: float = 0.03, device="cuda", training: bool = True, dtype: torch.dtype = torch.float32):
         """shapes: (B,C,H,W) of the P3/P4/P5 features; hidden: mask-head widths; cbam_params: per level (w1,b1,w2,b2,wsa,beta);
         head_states: per level a MGAMaskHead state_dict; target_hw: resolution of the segmentation targets (default: feature size);
-        bn_eps / bn_momentum: what Ultralytics' initialize_weights gives every BatchNorm2d (U/utils/torch_utils.py:570-572)."""
+        bn_eps / bn_momentum: what Ultralytics' initialize_weights gives every BatchNorm2d (U/utils/torch_utils.py:570-572);
+        dtype: element type of the FEATURES and their gradients (x, y, gy, gx: fp32 | fp16 | bf16).  The mask logits, the targets, every
+        statistic and every parameter gradient stay fp32: the heads emit fp32 logits directly (MGAHEAD_LOGITS_F32), which is what
+        MaskCBAM's mask input and the loss take -- no conversion pass anywhere in the slice."""
         self.lib = _lib.load()
         self.device = torch.device(device)
         dev = self.device
@@ -51,7 +54,9 @@ class SlicePlan:
                                       sd["proj.1.num_batches_tracked"].detach().to(dev).clone()))
         n_head = sum(p.numel() for ps in self.head_params for p in ps)
         self.grad_bucket = torch.zeros(n_cbam + n_head + 2, dtype=f32, device=dev)
-        self.cbam = PyramidPlan(shapes, cbam_params, cbam_cfgs, dtype=f32, device=dev, with_mask=True, want_gmask=True,
+        self.dtype = dtype
+        dcode = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}[dtype]
+        self.cbam = PyramidPlan(shapes, cbam_params, cbam_cfgs, dtype=dtype, device=dev, with_mask=True, want_gmask=True,
                                 grad_bucket=self.grad_bucket[:n_cbam])
         self.x, self.logits, self.y, self.gy, self.gx = self.cbam.x, self.cbam.mask, self.cbam.y, self.cbam.gy, self.cbam.gx
         off = n_cbam
@@ -96,7 +101,7 @@ class SlicePlan:
             F.x, F.logits, F.ctx, F.p = self.x[l].data_ptr(), self.logits[l].data_ptr(), self.head_ctx[l].data_ptr(), P
             F.ctx_bytes = Bw.ctx_bytes = self.head_ctx[l].numel()
             Bw.scratch_bytes = self.head_scratch[l].numel()
-            F.B, F.C, F.H, F.W, F.dtype = B, Cc, H, W, _lib.F32
+            F.B, F.C, F.H, F.W, F.dtype, F.flags = B, Cc, H, W, dcode, _lib.HEAD_LOGITS_F32
             gw1, gg, gb, gwh, gbh = self.head_grads[l]
             # dL/dlogits = the loss's part (seg_glogits) + MaskCBAM's dL/dmask (g_logits2): summed while the head's backward loads them
             Bw.x, Bw.g_logits, Bw.g_logits2, Bw.ctx, Bw.scratch, Bw.gx = (self.x[l].data_ptr(), self.seg_glogits[l].data_ptr(),
@@ -104,7 +109,7 @@ class SlicePlan:
                                                                           self.head_scratch[l].data_ptr(), self.gx[l].data_ptr())
             Bw.gw1, Bw.gbn_weight, Bw.gbn_bias, Bw.gwh, Bw.gbh = gw1.data_ptr(), gg.data_ptr(), gb.data_ptr(), gwh.data_ptr(), gbh.data_ptr()
             Bw.p = _head_params(w1, gamma, beta, rm, rv, None, wh, bh, hid, bn_eps, bn_momentum, training)
-            Bw.B, Bw.C, Bw.H, Bw.W, Bw.dtype, Bw.flags = B, Cc, H, W, _lib.F32, _lib.HEAD_BWD_ACCUM_GX
+            Bw.B, Bw.C, Bw.H, Bw.W, Bw.dtype, Bw.flags = B, Cc, H, W, dcode, _lib.HEAD_BWD_ACCUM_GX | _lib.HEAD_LOGITS_F32
 
     # ------------------------------------------------------------------------------------------------------------------------------
     def _stream(self):

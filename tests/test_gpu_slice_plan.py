@@ -82,3 +82,37 @@ def test_slice_plan_equals_the_module_composition(built_lib, shapes, hidden, tar
     graph.replay(); torch.cuda.synchronize()
     assert torch.equal(plan.y[0], y0) and not torch.equal(plan.head_buffers[0][0], rm)
     assert int(plan.head_buffers[0][2]) == 2
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+def test_slice_plan_with_half_precision_features(built_lib, dtype, tol):
+    """SlicePlan(dtype=fp16 | bf16): half-precision features and feature gradients, fp32 mask logits straight from the heads
+    (MGAHEAD_LOGITS_F32: no conversion pass between head, block and loss), fp32 statistics and parameter gradients -- against the fp32
+    plan on the same rounded inputs, at the tolerances of the half-precision I/O tests (BASELINE configs[4] is a bf16 config)."""
+    from mga_yolo_amd.slice import SlicePlan
+    shapes, hidden = [(4, 64, 16, 16), (4, 128, 8, 8), (4, 256, 4, 4)], [16, 32, 64]
+    heads, blocks = _build(shapes, hidden)
+    mk = lambda dt: SlicePlan(shapes, hidden, [b.block_params() for b in blocks], [b.block_config() for b in blocks],
+                              [{k: v.detach().clone() for k, v in h.state_dict().items()} for h in heads], scale_weights=(1.0, 0.5, 2.0), dtype=dt)
+    ref, plan = mk(torch.float32), mk(dtype)
+    assert plan.x[0].dtype == dtype and plan.gx[0].dtype == dtype and plan.logits[0].dtype == torch.float32
+    g = torch.Generator().manual_seed(33)
+    for l, (B, C, H, W) in enumerate(shapes):
+        x = torch.randn(B, C, H, W, generator=g).to(dtype)
+        gy = torch.randn(B, C, H, W, generator=g).to(dtype)
+        t = (torch.rand(B, 1, H, W, generator=g) > 0.7).float()
+        for p_ in (ref, plan):
+            p_.x[l].copy_(x); p_.gy[l].copy_(gy); p_.targets[l].copy_(t)
+    for p_ in (ref, plan):
+        p_.det_loss.copy_(torch.tensor([1.3, 0.7, 2.1])); p_.log_vars.copy_(torch.tensor([0.3, -0.4]))
+        p_.step()
+    torch.cuda.synchronize()
+    plan.check_handoff()
+    assert rel_err(plan.total, ref.total) < tol
+    for l in range(len(shapes)):
+        assert rel_err(plan.logits[l], ref.logits[l]) < tol and rel_err(plan.y[l].float(), ref.y[l]) < tol, l
+        assert rel_err(plan.gx[l].float(), ref.gx[l]) < 2 * tol, l
+    assert rel_err(plan.grad_bucket, ref.grad_bucket) < 2 * tol
+    g2 = plan.capture(plan.step)                                       # graph-capturable like the fp32 plan
+    g2.replay(); torch.cuda.synchronize()
+    plan.check_handoff()

@@ -34,7 +34,10 @@ GRAD_KEYS = ("gx", "gw1", "ggamma", "gbeta", "gwh", "gbh")
 # z ~ 1e4, the case that exposes a cancelling BatchNorm variance): dW1 = sum g_z x with sum g_z = 0 and x ~ 50 is a difference of large
 # terms; against a float64 evaluation of the same graph the reference's stored dW1 is 9.9e-5 off and a plain fp32 einsum 1.8e-4
 # (measured when the golden was made), everything else 5e-6.  Its dW1 is therefore compared at 5e-4; all other entries at the bar.
-LOOSE = {("dc_offset", "gw1"): 5e-4}
+LOOSE = {("dc_offset", "gw1"): 5e-4,
+         # hid192 (C = 768: sums of 768 products per output): the ORACLE's fp32 einsum against the reference's fp32 conv depends on the
+         # host's BLAS blocking -- 2e-5 holds on the build container's CPU, not on the GPU box's (EPYC 9575F); 1e-4 is the bar anyway
+         **{("hid192", k): 1e-4 for k in ("logits", "gx", "gw1", "ggamma", "gbeta", "gwh", "gbh", "running_mean", "running_var")}}
 _CASE = [None]
 
 
