@@ -23,6 +23,35 @@
 namespace mgacbam {
 
 typedef float v4f32 __attribute__((ext_vector_type(4)));
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef _Float16 v4f16 __attribute__((ext_vector_type(4)));
+typedef __bf16 v4bf16 __attribute__((ext_vector_type(4)));
+
+// Half-precision features take the matrix cores' NATIVE rate: v_mfma_f32_16x16x16_{f16,bf16} (K = 16 per instruction at 16 cycles per
+// SIMD against K = 4 at 32 for the fp32 form: 8x the MAC rate), fp32 accumulation.  Lane l supplies row / column l % 16 and the FOUR
+// consecutive k 4 (l / 16) .. +3 of each operand -- the grouping the fp32 kernels already load in (a lane's 16-byte weight vector, its
+// four channel rows), so the operands are the fp32 values the loads produced, packed pairwise (v_cvt_pk_*): feature values are half
+// already (exact), the fp32 weights and g_z are rounded to the feature type (2^-11 / 2^-8 relative, inside the half-precision bars).
+template <typename T> struct HalfMma { static constexpr bool on = false; };
+#ifndef MGAHEAD_HALF_MMA
+#define MGAHEAD_HALF_MMA 1      // A/B builds: 0 = half features through the fp32 MFMA (round 2's path)
+#endif
+template <> struct HalfMma<__half> {
+  static constexpr bool on = MGAHEAD_HALF_MMA != 0;
+  __device__ static __forceinline__ v4f32 mma(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3, v4f32 c) {
+    const v4f16 a = {static_cast<_Float16>(a0), static_cast<_Float16>(a1), static_cast<_Float16>(a2), static_cast<_Float16>(a3)};
+    const v4f16 b = {static_cast<_Float16>(b0), static_cast<_Float16>(b1), static_cast<_Float16>(b2), static_cast<_Float16>(b3)};
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct HalfMma<bf16_t> {
+  static constexpr bool on = MGAHEAD_HALF_MMA != 0;
+  __device__ static __forceinline__ v4f32 mma(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3, v4f32 c) {
+    const v4bf16 a = {static_cast<__bf16>(a0), static_cast<__bf16>(a1), static_cast<__bf16>(a2), static_cast<__bf16>(a3)};
+    const v4bf16 b = {static_cast<__bf16>(b0), static_cast<__bf16>(b1), static_cast<__bf16>(b2), static_cast<__bf16>(b3)};
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(v4i16, a), __builtin_bit_cast(v4i16, b), c, 0, 0, 0);
+  }
+};
 
 struct HeadGeo {
   int B, C, hid, H, W, HW;
@@ -123,9 +152,13 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
   // 4 CONSECUTIVE floats of a W1 row -- lane (lk, ln) at step 4q + r takes channel 16q + 4lk + r -- one 16-byte load instead of four
   // gathers of 16 cache lines each (those made the TA, not HBM, the limit of the levels with long K); groups are whole per wave
   const bool wperm = !GX && (g.C & 3) == 0;
-  const int ksteps = wperm ? ((K + 15) >> 4) << 2 : (K + 3) >> 2;
+  // half-precision gx: the same grouping of K (a lane's four CONSECUTIVE hidden channels per group of 16), so that four K steps of a lane
+  // are one bf16 / fp16 MFMA operand (HalfMma above); its weights W1[k][out] stay per-element gathers, as in the fp32 form
+  const bool half_gx = GX && HalfMma<T>::on;
+  const bool grp = wperm || half_gx;
+  const int ksteps = grp ? ((K + 15) >> 4) << 2 : (K + 3) >> 2;
   int kper_ = (ksteps + KW - 1) / KW;                           // this wave's share of the K steps: [kbeg, kend)
-  if (wperm) kper_ = (kper_ + 3) & ~3;
+  if (grp) kper_ = (kper_ + 3) & ~3;
   const int kper = kper_;
   const int kbeg = kwi * kper, kend = min(ksteps, kbeg + kper);
   const int gid = A.trace_base + blockIdx.x;
@@ -167,6 +200,29 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
             for (int r = 0; r < 4; ++r) aw[4 * gi + r][t] = w4[r];
           }
         }
+      } else if (half_gx) {
+#pragma unroll
+        for (int gi = 0; gi < KU / 4; ++gi) {
+          const int kk0 = ((ks0 >> 2) + gi) * 16 + 4 * lk;      // this lane's 4 hidden channels of the group
+          const bool gok = ks0 + 4 * gi < kend;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kk = kk0 + r, u = 4 * gi + r;
+            const bool kok = gok && kk < K;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) { bv[u][q] = 0.f; zq[GX ? u : 0][q] = 0.f; }
+            if (kok && px_ok) {
+              load_vec<float, VEC>(gab + static_cast<size_t>(kk) * g.HW, bv[u]);
+              load_vec<float, VEC>(zb + static_cast<size_t>(kk) * g.HW, zq[GX ? u : 0]);
+            }
+#pragma unroll
+            for (int t = 0; t < MTW; ++t) {
+              const int mt = mw * MTW + t;
+              const int out = (mt0 + mt) * 16 + ln;
+              aw[u][t] = (kok && mt < mtn && out < M) ? A.p.w1[static_cast<size_t>(kk) * g.C + out] : 0.f;
+            }
+          }
+        }
       } else {
 #pragma unroll
       for (int u = 0; u < KU; ++u) {
@@ -198,18 +254,38 @@ __device__ __forceinline__ void head_gemm_body(const HeadArgs& A, const int wg, 
       for (int u = 0; u < KU; ++u) {
         if (ks0 + u < kend) {                                   // uniform per wave
           if (GX) {                                             // g_z = k_j (g_a - gbeta_j/n - zhat gamma'_j/n), zhat = (z - mean) rstd
-            const int kk = min((ks0 + u) * 4 + lk, g.hidp - 1);
+            const int kk = min(half_gx ? ((ks0 + u) >> 2) * 16 + 4 * lk + ((ks0 + u) & 3) : (ks0 + u) * 4 + lk, g.hidp - 1);
             const float kj = s_kst[kk], mean = s_kst[g.hidp + kk], rstd = s_kst[2 * g.hidp + kk];
             const float gbn = s_kst[3 * g.hidp + kk], ggn = s_kst[4 * g.hidp + kk];
 #pragma unroll
             for (int r = 0; r < VEC; ++r) bv[u][r] = kj * (bv[u][r] - gbn - (zq[u][r] - mean) * rstd * ggn);
             // (lanes whose loads were skipped hold g_a = z = 0: their g_z meets a ZERO weight, or its result row is never stored)
           }
+          if (!(HalfMma<T>::on && grp)) {                       // fp32 MFMA: one K step (4 channels over the lane groups) per instruction
 #pragma unroll
-          for (int t = 0; t < MTW; ++t) {
-            if (mw * MTW + t < mtn) {                       // uniform per wave
+            for (int t = 0; t < MTW; ++t) {
+              if (mw * MTW + t < mtn) {                       // uniform per wave
 #pragma unroll
-              for (int r = 0; r < VEC; ++r) acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[u][t], bv[u][r], acc[t][r], 0, 0, 0);
+                for (int r = 0; r < VEC; ++r) acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[u][t], bv[u][r], acc[t][r], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+      if constexpr (HalfMma<T>::on) {
+        if (grp) {                                              // half-precision features: four K steps of a lane = ONE 16x16x16 MFMA
+#pragma unroll
+          for (int gi = 0; gi < KU / 4; ++gi) {
+            if (ks0 + 4 * gi < kend) {                          // uniform per wave
+#pragma unroll
+              for (int t = 0; t < MTW; ++t) {
+                if (mw * MTW + t < mtn) {
+#pragma unroll
+                  for (int r = 0; r < VEC; ++r)
+                    acc[t][r] = HalfMma<T>::mma(aw[4 * gi][t], aw[4 * gi + 1][t], aw[4 * gi + 2][t], aw[4 * gi + 3][t],
+                                                bv[4 * gi][r], bv[4 * gi + 1][r], bv[4 * gi + 2][r], bv[4 * gi + 3][r], acc[t][r]);
+                }
+              }
             }
           }
         }
@@ -897,9 +973,14 @@ __device__ __forceinline__ void head_bwd_gw_body(const HeadArgs& A, const int wg
         for (int t = 0; t < kHeadMTW; ++t) {
           if (t < mtn) {
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
+            for (int n = 0; n < NT; ++n) {
+              if constexpr (HalfMma<T>::on && VEC == 4) {        // a lane's 4 pixels = one K group of the half-precision MFMA
+                acc[t][n] = HalfMma<T>::mma(av[h][t][0], av[h][t][1], av[h][t][2], av[h][t][3], bv[h][n][0], bv[h][n][1], bv[h][n][2], bv[h][n][3], acc[t][n]);
+              } else {
 #pragma unroll
-              for (int r = 0; r < VEC; ++r) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][t][r], bv[h][n][r], acc[t][n], 0, 0, 0);
+                for (int r = 0; r < VEC; ++r) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][t][r], bv[h][n][r], acc[t][n], 0, 0, 0);
+              }
+            }
           }
         }
       }
@@ -1032,8 +1113,12 @@ __device__ __forceinline__ void head_bwd_gw2_body(const HeadArgs& A, const int w
         if (t < MT) {                                           // uniform
           float aq[4];
           load_vec<float, 4>(s_g + (t * 16 + lr) * kHeadGwPitch + sp * 16 + 4 * lq, aq);
+          if constexpr (HalfMma<T>::on) {
+            acc[t] = HalfMma<T>::mma(aq[0], aq[1], aq[2], aq[3], bq[0], bq[1], bq[2], bq[3], acc[t]);
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[r], bq[r], acc[t], 0, 0, 0);
+            for (int r = 0; r < 4; ++r) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[r], bq[r], acc[t], 0, 0, 0);
+          }
         }
       }
     }
