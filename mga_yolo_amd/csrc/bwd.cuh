@@ -38,6 +38,14 @@ constexpr int kPghLds = 2048;   // floats of LDS for k_bwd_reduce2's hidden-grad
 #define MGACBAM_BAPPLY_UN 2
 #endif
 
+// A/B hook: occupancy cap of the two read-only backward kernels (-DMGACBAM_BWD_WAVES=4: what they would get inside one launch with
+// k_bwd_apply, whose 104 VGPRs allow 4 waves per SIMD)
+#ifdef MGACBAM_BWD_WAVES
+#define BWD_OCC __attribute__((amdgpu_waves_per_eu(MGACBAM_BWD_WAVES, MGACBAM_BWD_WAVES)))
+#else
+#define BWD_OCC
+#endif
+
 namespace mgacbam {
 
 // ---------------------------------------------------------------------------------------------
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_convT(const Group<BwdArgs> G) {
 // latency-bound conv overlaps the streaming tail and one launch boundary disappears.  Flags: one generation counter per k_bwd_reduce1
 // tile and per conv tile in ctx.sync (zero-filled by the caller once, never reset: see bwd_convT_body).
 template <typename T, int VEC, int K>
-__global__ __launch_bounds__(kBlock) void k_bwd_reduce1_fold(const Group<BwdArgs> G) {
+__global__ __launch_bounds__(kBlock) BWD_OCC void k_bwd_reduce1_fold(const Group<BwdArgs> G) {
   extern __shared__ __align__(16) float smem[];
   int local;
   const int l = find_level(G, blockIdx.x, local);
@@ -438,7 +446,7 @@ __device__ __forceinline__ void bwd_reduce2_body(const BwdArgs& A, const int bid
 // ROLES: the level's grid is [nwsa dWsa-partial workgroups (k = 7)][streaming workgroups]: the LDS/VALU-bound role
 // workgroups are dispatched first and overlap with the HBM-bound ones instead of costing a launch on the critical path.
 template <typename T, int VEC, int CPT, bool ROLES>
-__global__ __launch_bounds__(kBlock) void k_bwd_reduce2(const Group<BwdArgs> G) {
+__global__ __launch_bounds__(kBlock) BWD_OCC void k_bwd_reduce2(const Group<BwdArgs> G) {
   extern __shared__ __align__(16) float smem[];                // [64 reduction scratch][TY * hidden] | wsa tiles
   int local;
   const int l = find_level(G, blockIdx.x, local);
