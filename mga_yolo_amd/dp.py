@@ -41,23 +41,26 @@ class GradExchange:
     gradients, which DDP puts through the same collective every step, U/engine/trainer.py:366-367): the buckets are reduced one
     after the other on ONE side stream, in order -- what DDP's reducer does with its ready buckets."""
 
-    def __init__(self, bucket, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, bucket, group: Optional[dist.ProcessGroup] = None, single_rank_collective: bool = False):
         self.buckets = list(bucket) if isinstance(bucket, (list, tuple)) else [bucket]
         self.bucket = self.buckets[0]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # single_rank_collective: issue the collective even in a one-rank group (a no-op numerically).  For tests: it is the only way to run
+        # the RCCL branch -- ReduceOp.AVG inside the collective, side stream, event join -- on a one-GPU box
+        self.always = bool(single_rank_collective and dist.is_initialized())
         self.on_gpu = self.bucket.is_cuda
         self.side = torch.cuda.Stream(self.bucket.device) if self.on_gpu else None
         self._ready = torch.cuda.Event() if self.on_gpu else None
         self._work = None
         # RCCL averages inside the collective (one kernel fewer on the side stream than SUM + div_); gloo has no AVG
-        self.avg_in_collective = bool(self.on_gpu and self.world > 1 and dist.get_backend(group) == "nccl")
+        self.avg_in_collective = bool(self.on_gpu and (self.world > 1 or self.always) and dist.get_backend(group) == "nccl")
 
     def nbytes(self) -> int:
         return sum(b.numel() * b.element_size() for b in self.buckets)
 
     def start(self):
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return
         if self.on_gpu:
             cur = torch.cuda.current_stream(self.bucket.device)
@@ -70,7 +73,7 @@ class GradExchange:
             self._work = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
 
     def finish(self):
-        if self.world == 1 or self._work is None:
+        if (self.world == 1 and not self.always) or self._work is None:
             return
         if self.on_gpu:
             with torch.cuda.stream(self.side):

@@ -860,3 +860,54 @@ def test_dwsa_tail_roles_give_the_same_bits(F, monkeypatch):
         _lib.reload_env()
     assert torch.equal(base[0], tail[0]) and all(torch.equal(a, b) for a, b in zip(base[1], tail[1]))
     assert all(int(w.abs().sum()) == 0 for w in tail[2]), "arrival counters must be back at 0 between calls"
+
+
+def test_rccl_branch_of_the_gradient_exchange_runs_on_this_gpu(F):
+    """`GradExchange`'s "nccl" (= RCCL) branch -- ReduceOp.AVG inside the collective, launched on a side stream behind an event, joined
+    back into the compute stream -- on hardware.  A one-GPU box cannot host two RCCL ranks, so this is a ONE-rank group with the
+    collective forced (numerically the identity): it proves the branch executes and orders correctly against the compute stream (the
+    bucket is written by a kernel right before start() and read right after finish()), not that two GPUs agree -- that needs the node."""
+    import os
+    import torch.distributed as dist
+    from mga_yolo_amd.dp import GradExchange, payload_buckets
+    from mga_yolo_amd.plan import PyramidPlan
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29650 + os.getpid() % 200))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        shapes = [(4, 64, 20, 20), (4, 128, 10, 10)]
+        params, cfgs = [], []
+        for l, (B, C, H, W) in enumerate(shapes):
+            p = O.Params.default_init(C, seed=l)
+            params.append((p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta)); cfgs.append(F.BlockConfig(hidden=p.w1.shape[0]))
+        plan = PyramidPlan(shapes, params, cfgs)
+        for l, (B, C, H, W) in enumerate(shapes):
+            x, mask, gy = synth(B, C, H, W, seed=70 + l)
+            plan.x[l].copy_(x); plan.mask[l].copy_(mask); plan.gy[l].copy_(gy)
+        plan.forward(); plan.backward()
+        torch.cuda.synchronize()
+        want = plan.grad_bucket.clone()
+        payload = payload_buckets(3 * (1 << 20), plan.grad_bucket.device, cap_mb=1.0)      # three 1 MB buckets beside the blocks' own
+        for i, b in enumerate(payload):
+            b.fill_(float(i + 1))
+        ex = GradExchange([plan.grad_bucket] + payload, single_rank_collective=True)
+        assert ex.avg_in_collective and ex.side is not None
+        for _ in range(3):
+            plan.grad_bucket.zero_()
+            plan.forward(); plan.backward()                    # writes the bucket on the compute stream ...
+            ex.start()                                         # ... the collective waits for exactly that point
+            plan.forward(_lib_pool())                          # parameter-free work overlapping the exchange, as bench.py does
+            ex.finish()
+            got = plan.grad_bucket.clone()                     # ordered after the collective by finish()
+            torch.cuda.synchronize()
+            assert torch.equal(got, want)
+        assert all(float(b[0]) == i + 1 and float(b[-1]) == i + 1 for i, b in enumerate(payload))
+    finally:
+        dist.destroy_process_group()
+
+
+def _lib_pool():
+    from mga_yolo_amd import _lib
+    return _lib.FWD_STAGES["pool"]
