@@ -53,9 +53,9 @@ MODEL_SCALE = {"cfg3": "s", "cfg4": "m"}
 
 # algorithmic bytes of each HBM-bound kernel in units of E*w (feature-sized tensors it must read or write once)
 FWD_KERNEL_E = {"pool": 1, "chan": 1, "apply": 2, "gate": 2}   # k_gate = chan + apply with x resident: read x once, write y
-BWD_KERNEL_E = {"reduce1": 2, "reduce2": 1, "apply": 3}
+BWD_KERNEL_E = {"reduce1": 2, "reduce2": 1, "apply": 3, "r12": 3}   # r12 = reduce1 + reduce2 in one launch (k_bwd_r12): x, gy, x
 KERNEL_SYMBOL_FOLD = {"bwd.reduce1": "k_bwd_reduce1_fold"}
-KERNEL_SYMBOL = {"fwd.pool": "k_pool", "fwd.chan": "k_chan", "fwd.apply": "k_apply", "fwd.gate": "k_gate", "bwd.reduce1": "k_bwd_reduce1",
+KERNEL_SYMBOL = {"bwd.r12": "k_bwd_r12", "fwd.pool": "k_pool", "fwd.chan": "k_chan", "fwd.apply": "k_apply", "fwd.gate": "k_gate", "bwd.reduce1": "k_bwd_reduce1",
                  "bwd.reduce2": "k_bwd_reduce2", "bwd.apply": "k_bwd_apply", "bwd.convT": "k_bwd_convT"}
 
 
@@ -123,17 +123,25 @@ def time_kernels(plan, reps):
     else:
         fwd += [("fwd.chan", plan.forward, Fs["chan"]), ("fwd.apply", plan.forward, Fs["apply"])]
     folded = plan.fold_active()
-    if folded:                   # the transposed conv rides at the end of the k_bwd_reduce1 launch (one launch, as in the real step)
+    fold_bit = _lib.BWD_FOLD if plan.fold_backward else 0
+    wsa_tail = os.environ.get("MGACBAM_WSA_TAIL", "0") == "1"
+    # the real step's backward (one mgacbam_backward call) is TWO launches when the fold applies: k_bwd_r12 (k_bwd_reduce1 tiles,
+    # transposed-conv tiles, dWsa tiles and k_bwd_reduce2 sweeps with in-launch hand-offs) and k_bwd_apply
+    merged = folded and all(c.k == 7 for c in plan.cfgs) and os.environ.get("MGACBAM_BWD_MERGE", "1") != "0" and not wsa_tail
+    if merged:
+        seq = fwd + [("bwd.r12", plan.backward, Bs["reduce1"] | Bs["convT"] | Bs["reduce2"] | Bs["wsa"] | _lib.BWD_FUSE | _lib.BWD_FOLD),
+                     ("bwd.apply", plan.backward, Bs["params"] | Bs["apply"] | _lib.BWD_FUSE | fold_bit)]
+    elif folded:                 # the transposed conv rides at the end of the k_bwd_reduce1 launch (one launch, as in the real step)
         bwd = [("bwd.reduce1", plan.backward, Bs["reduce1"] | Bs["convT"] | _lib.BWD_FOLD)]
     else:
         bwd = [("bwd.reduce1", plan.backward, Bs["reduce1"]), ("bwd.convT", plan.backward, Bs["convT"])]
-    fold_bit = _lib.BWD_FOLD if plan.fold_backward else 0
     # the two fused launches: streaming workgroups + role workgroups.  With the zero-filled hand-off state (fold_bit) the dWsa tile partials
     # are the LAST workgroups of the k_bwd_apply launch, as in the real step (one mgacbam_backward call); else leading roles of k_bwd_reduce2
-    wsa_in_apply = Bs["wsa"] if (fold_bit and os.environ.get("MGACBAM_WSA_TAIL", "0") == "1") else 0
-    seq = fwd + bwd + [
-           ("bwd.reduce2", plan.backward, Bs["reduce2"] | (Bs["wsa"] ^ wsa_in_apply) | _lib.BWD_FUSE),
-           ("bwd.apply", plan.backward, Bs["params"] | Bs["apply"] | wsa_in_apply | _lib.BWD_FUSE | fold_bit)]
+    wsa_in_apply = Bs["wsa"] if (fold_bit and wsa_tail) else 0
+    if not merged:
+        seq = fwd + bwd + [
+               ("bwd.reduce2", plan.backward, Bs["reduce2"] | (Bs["wsa"] ^ wsa_in_apply) | _lib.BWD_FUSE),
+               ("bwd.apply", plan.backward, Bs["params"] | Bs["apply"] | wsa_in_apply | _lib.BWD_FUSE | fold_bit)]
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(seq) + 1)] for _ in range(reps)]
     for _ in range(3):
         for _, fn, mask in seq:
@@ -433,7 +441,7 @@ def main():
     kernels = {}
     event_pad = kt.pop("_event_pad_us")
     fast75 = kt.pop("_fast75")
-    symbols = dict(KERNEL_SYMBOL, **(KERNEL_SYMBOL_FOLD if kt.pop("_folded") else {}))
+    symbols = dict(KERNEL_SYMBOL, **(KERNEL_SYMBOL_FOLD if kt.pop("_folded") else {}))   # (bwd.r12 has its own entry)
     for name, us in kt.items():
         side, k = name.split(".")
         mult = (FWD_KERNEL_E if side == "fwd" else BWD_KERNEL_E).get(k)

@@ -132,7 +132,8 @@ typedef struct mgacbam_ctx_layout {
   int64_t proj;     /* (B,hid,HW) W1-projection of x, only when hid <= MGACBAM_PROJ_MAX_HIDDEN (else empty)  */
   int64_t sync;     /* int32 hand-off state, generation counters that are never reset: (B, ceil(HW/16)+1) tile flags of MGACBAM_FWD_FUSE
                        (see there), 4 status words ([0] time-out, [1] [2] arrival counters of the dWsa tail roles: 0 between calls), (B) ca
-                       flags, 2 x (B, ceil(HW/16)+1) MGACBAM_BWD_FOLD tile / conv-tile flags */
+                       flags, 2 x (B, ceil(HW/16)+1) MGACBAM_BWD_FOLD tile / conv-tile flags; the merged backward launch's own 3 x (B, ceil(HW/16)+1)
+                       tile / conv-tile / dWsa-tile flags and (B, C) sweep flags */
   int64_t total;    /* == mgacbam_ctx_bytes()                                                 */
   int64_t status;   /* int32 status word inside `sync`: 0 = every in-launch hand-off of every call on this ctx completed; non-zero =
                        one timed out (that tile's outputs were poisoned with NaN).  The caller reads these 4 bytes wherever it
@@ -200,6 +201,10 @@ enum {
                                  state.  The conv tiles wait only for lower-numbered workgroups that never wait themselves, so
                                  progress does not depend on residency; a time-out still poisons (NaN g_planes -> gx) and sets
                                  the status word.  Not part of MGACBAM_BWD_ALL: mgacbam_backward() works on an un-zeroed ctx.
+                                 With REDUCE2 + WSA + FUSE in the same call as well (mgacbam_backward_stages(MGACBAM_BWD_ALL | MGACBAM_BWD_FOLD):
+                                 the whole backward), spatial kernel 7: REDUCE1, CONVT, WSA and REDUCE2 are ONE launch (k_bwd_r12) -- the
+                                 sweeps of a sample wait for its conv tiles inside the launch; generation counters of its own in ctx.sync,
+                                 so both launch forms may alternate on one ctx.  The backward is then 2 launches (4 per step).
                                  Knob MGACBAM_WSA_TAIL=1 (opt-in, measured slower at BASELINE configs[1]): with WSA + PARAMGRAD + APPLY +
                                  FUSE in the same call the flag also moves the dWsa tile partials from the front of the REDUCE2 launch
                                  to the END of the APPLY launch, followed by the workgroups that sum them in the fixed order (bitwise

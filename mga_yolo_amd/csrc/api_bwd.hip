@@ -47,6 +47,9 @@ static int backward_args(const mgacbam_bwd_level_t& L, BwdArgs& A, Sig& sig) {
   A.nflag = static_cast<int>(sync_flags(static_cast<size_t>(L.H) * L.W));
   A.bflag0 = L.B * A.nflag + 4 + L.B;
   A.cflag0 = A.bflag0 + L.B * A.nflag;
+  A.mbflag0 = A.cflag0 + L.B * A.nflag; A.mcflag0 = A.mbflag0 + L.B * A.nflag;
+  A.wflag0 = A.mcflag0 + L.B * A.nflag; A.sflag0 = A.wflag0 + L.B * A.nflag;
+  A.merged = 0;
   A.vec = VEC;
   { const Knobs kn = knobs(); A.trace = kn.trace; A.spin_limit = kn.spin_limit; }
   const int proj = (L.flags & MGACBAM_BWD_HAVE_PROJ) && L.gmask != nullptr;
@@ -80,7 +83,41 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
     fold = TP >= kSyncPx && TP >= lv[l].g.W && 8 * (((lv[l].t.conv_th + lv[l].g.k) * lv[l].g.W + TP - 1) / TP + 1) <= 512 &&
            lv[l].nconv <= lv[l].g.B * lv[l].nflag;                 // one flag per conv tile fits the region reserved in ctx.sync
   }
-  if (fold) {
+  // k_bwd_r12: the folded launch AND k_bwd_reduce2 with its dWsa roles as one launch (bwd.cuh), when both stages are in this call
+  const bool fuse_early = (stages & MGACBAM_BWD_FUSE) != 0;
+  const bool tail_early = fuse_early && (stages & MGACBAM_BWD_APPLY) && (stages & MGACBAM_BWD_PARAMGRAD) && (stages & MGACBAM_BWD_WSA) && sig.k == 7 &&
+                          knobs().wsa_tail;
+  bool merge = fold && fuse_early && (stages & MGACBAM_BWD_REDUCE2) && (stages & MGACBAM_BWD_WSA) && sig.k == 7 && !tail_early && knobs().bwd_merge &&
+               !knobs().wsa_fat;
+  for (int l = 0; l < n && merge; ++l) merge = lv[l].nwsa <= lv[l].g.B * lv[l].nflag && lv[l].ncg <= lv[l].g.C && lv[l].nconv % lv[l].g.B == 0;
+  if (merge) {
+    R12Group R;
+    R.g.n = n;
+    size_t smem = 0;
+    for (int l = 0; l < n; ++l) {
+      lv[l].merged = 1; lv[l].bflag0 = lv[l].mbflag0; lv[l].cflag0 = lv[l].mcflag0; lv[l].nrole = lv[l].nwsa;
+      R.g.lv[l] = lv[l];
+      smem = std::max({smem, reduce1_smem(lv[l].g, sig.vec), convT_smem(lv[l].t, sig.k), wsa_smem(lv[l].t, sig.k),
+                       (64 + static_cast<size_t>(std::max(kPghLds, kBlock / lv[l].t.pool_tx))) * sizeof(float)});
+    }
+    int tot = 0;
+    for (int p = 0; p < 4; ++p) {
+      for (int l = 0; l < n; ++l) {
+        R.seg[p][l] = tot;
+        tot += p == 0 ? xcd_grid(lv[l].g.B, lv[l].nt) : p == 1 ? pad8(lv[l].nconv) : p == 2 ? pad8(lv[l].nwsa) : sweep_blocks(lv[l], lv[l].t.pool_tx, cpt);
+      }
+      R.seg[p][n] = tot;
+    }
+    const int grid = tot;
+#define CALL_R12B(CPTV) LAUNCH((k_bwd_r12<TT, VV, CPTV>), grid, smem, st, R)
+#define CALL_R12(Tt, Vv) { using TT = Tt; constexpr int VV = Vv; DISPATCH_CPT(cpt, CALL_R12B); }
+    DISPATCH_T_VEC(sig.dtype, sig.vec, CALL_R12);
+#undef CALL_R12
+#undef CALL_R12B
+    if (int e = launch_status("k_bwd_r12")) return e;
+    for (int l = 0; l < n; ++l) G.lv[l] = lv[l];                  // (the later launches of this call see the same level state)
+  }
+  if (fold && !merge) {
     size_t smem = 0;
     for (int l = 0; l < n; ++l) smem = std::max({smem, reduce1_smem(lv[l].g, sig.vec), convT_smem(lv[l].t, sig.k)});
     const int grid = fill([&](const BwdArgs& a) { return xcd_grid(a.g.B, a.nt) + pad8(a.nconv); });
@@ -118,7 +155,7 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
   const bool wsa_tail = fuse_pg && (stages & MGACBAM_BWD_FOLD) && (stages & MGACBAM_BWD_WSA) && sig.k == 7 && knobs().wsa_tail;
   const bool fuse_wsa = fuse && (stages & MGACBAM_BWD_REDUCE2) && (stages & MGACBAM_BWD_WSA) && sig.k == 7 && !wsa_tail;
   if (wsa_tail) for (int l = 0; l < n; ++l) { lv[l].wsa_tail = 1; G.lv[l].wsa_tail = 1; }
-  if (stages & MGACBAM_BWD_REDUCE2) {  // 3. rest of g_ca (needs g_planes), g_z [+ dWsa partials as role workgroups]
+  if ((stages & MGACBAM_BWD_REDUCE2) && !merge) {  // 3. rest of g_ca (needs g_planes), g_z [+ dWsa partials as role workgroups]
     size_t smem = 0;
     for (int l = 0; l < n; ++l) {
       smem = std::max(smem, (64 + static_cast<size_t>(std::max(kPghLds, kBlock / lv[l].t.pool_tx))) * sizeof(float));
@@ -156,7 +193,7 @@ static int backward_group(BwdArgs* lv, int n, const Sig& sig, int stages, hipStr
 #undef CALL_R22
     if (int e = launch_status("k_bwd_reduce2")) return e;
   }
-  if ((stages & MGACBAM_BWD_WSA) && !fuse_wsa && !wsa_tail) {  // 4. dWsa tile partials (depends on stage 1 only)
+  if ((stages & MGACBAM_BWD_WSA) && !fuse_wsa && !wsa_tail && !merge) {  // 4. dWsa tile partials (depends on stage 1 only)
     size_t smem = 0;
     for (int l = 0; l < n; ++l) smem = std::max(smem, wsa_smem(lv[l].t, sig.k));
     const int grid = fill([&](const BwdArgs& a) { return a.nwsa; });

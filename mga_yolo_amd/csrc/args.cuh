@@ -85,6 +85,10 @@ struct BwdArgs {
   int nflag;    // flags per sample in c.sync
   int bflag0;   // first backward hand-off flag in c.sync (ints): [B][nflag], one per k_bwd_reduce1 tile
   int cflag0;   // first flag of the folded transposed-conv tiles in c.sync: [nconv], generation counters like the tile flags
+  int wflag0;   // ... of the dWsa tile roles when they ride in the merged launch: [nwsa]
+  int sflag0;   // ... of k_bwd_reduce2's sweep workgroups in the merged launch: [B][C] (a sample's channel groups are its first ncg entries)
+  int mbflag0, mcflag0;   // the merged launch's own tile / conv-tile flags (the host puts them into bflag0 / cflag0 for that launch)
+  int merged;   // 1: k_bwd_reduce1 tiles, transposed-conv tiles, dWsa tiles and k_bwd_reduce2 sweeps are ONE launch (k_bwd_r12)
   unsigned spin_limit;
   int vec;      // elements per lane of the tile kernels (TP = chan_tx * vec pixels per tile)
   int wsa_tail; // 1: the dWsa tile partials and their sums are the LAST workgroups of the k_bwd_apply launch (arrival counters = status

@@ -105,7 +105,8 @@ __device__ __forceinline__ void bwd_reduce1_body(const BwdArgs& A, const int bid
   __syncthreads();
   // this tile's partials of A[b,c] and D[b,c], written as two contiguous runs of C floats (layout (B, nt, 2, C))
   float* part = A.s.A_part + (static_cast<size_t>(b) * ntile + tile) * 2 * g.C;
-  for (int c = tid; c < 2 * g.C; c += kBlock) part[c] = s_aq[c];
+  if (FOLD && A.merged) { for (int c = tid; c < 2 * g.C; c += kBlock) st_agent(part + c, s_aq[c]); }   // read by this launch's sweep workgroups
+  else { for (int c = tid; c < 2 * g.C; c += kBlock) part[c] = s_aq[c]; }
   if (ty == 0 && active) {
     for (int r = 1; r < TY; ++r) {
       const int o = (r * TX + tx) * VEC;
@@ -161,20 +162,23 @@ __device__ __forceinline__ void bwd_convT_body(const BwdArgs& A, const int local
     const int ra = max(c.y0 - c.pad, 0), rb = min(c.y0 + c.TH - 1 + c.pad, g.H - 1);
     bad = handoff_wait(A.c.sync + A.bflag0 + static_cast<size_t>(c.b) * A.nflag, (ra * g.W) / TP, ((rb + 1) * g.W - 1) / TP, gen,
                        A.c.sync + static_cast<size_t>(g.B) * A.nflag, A.spin_limit);
-    if (tid == 0) __hip_atomic_fetch_add(own, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && !A.merged) __hip_atomic_fetch_add(own, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   stage_window<8>(tg, 1, c.PH, c.PW, c.y0 - c.pad, c.x0 - c.pad, g, [&](int, int off) { return COH ? ld_agent(gpre + off) : gpre[off]; });
   __syncthreads();
   const int TWQ = A.t.conv_twq;
   const int py = tid / TWQ, q = tid - py * TWQ;
   constexpr int KK = K ? K : 1;
-  if (py >= c.TH) return;
+  const bool publish = COH && A.merged;                        // merged launch: the sweep workgroups of this sample wait for this tile
+  if (py >= c.TH && !publish) return;
   float acc[3][4];
 #pragma unroll
   for (int p = 0; p < 3; ++p)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[p][e] = 0.f;
-  if (K) {
+  if (py >= c.TH) {
+    // (idle rows of the thread grid: nothing to accumulate; they only take part in the publish barrier)
+  } else if (K) {
 #pragma unroll 1
     for (int i = 0; i < KK; ++i) {
       const float* row = tg + (py + i) * c.PW + q * 4;
@@ -206,17 +210,21 @@ __device__ __forceinline__ void bwd_convT_body(const BwdArgs& A, const int local
     }
   }
   const int yg = c.y0 + py;
-  if (yg < g.H) {
+  if (py < c.TH && yg < g.H) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int xg = c.x0 + q * 4 + e;
       if (xg < g.W) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-          A.s.gplanes[(static_cast<size_t>(c.b) * 3 + p) * g.HW + yg * g.W + xg] = bad ? __builtin_nanf("") : acc[p][e];   // NaN: timed-out hand-off
+        for (int p = 0; p < 3; ++p) {
+          float* dst = A.s.gplanes + (static_cast<size_t>(c.b) * 3 + p) * g.HW + yg * g.W + xg;
+          const float v = bad ? __builtin_nanf("") : acc[p][e];                                                       // NaN: timed-out hand-off
+          if (publish) st_agent(dst, v); else *dst = v;
+        }
       }
     }
   }
+  if (publish) handoff_publish(A.c.sync + A.cflag0 + local);
 }
 
 template <int K>
@@ -254,8 +262,8 @@ __global__ __launch_bounds__(kBlock) BWD_OCC void k_bwd_reduce1_fold(const Group
 //   through LDS.  K == 0 (any odd k): one thread per output.
 //   LDS: [g_pre tile][3 plane tiles][items * k partial sums]
 // ---------------------------------------------------------------------------------------------
-template <int K, bool AGENT = false>   // AGENT: the partials are summed inside the same launch (k_bwd_apply's tail roles): written through
-__device__ __forceinline__ void bwd_wsa_body(const BwdArgs& A, const int local, float* smem) {
+template <int K, bool AGENT = false, bool COH = false>   // AGENT: the partials are summed inside the same launch (k_bwd_apply's tail roles): written through
+__device__ __forceinline__ void bwd_wsa_body(const BwdArgs& A, const int local, float* smem) {   // COH: g_pre is published inside this launch (k_bwd_r12)
   const Geo& g = A.g;
   const int k = K ? K : g.k;
   const ConvTile c = conv_tile(g, A.t, k, local, A.t.wsa_th);
@@ -266,8 +274,18 @@ __device__ __forceinline__ void bwd_wsa_body(const BwdArgs& A, const int local, 
   float* accs = tp + 3 * plane_elems;          // (3*k*TH) x k row partials
   const float* gpre = A.s.gpre + static_cast<size_t>(c.b) * g.HW;
   const float* pl = A.c.planes + static_cast<size_t>(c.b) * 3 * g.HW;
+  bool bad = false;
+  if (COH) {                                                    // as the folded transposed conv: own generation counter, bounded wait
+    int* own = A.c.sync + A.wflag0 + local;
+    const int gen = static_cast<int>(static_cast<unsigned>(ld_agent(own)) + 1u);
+    const int TP = A.t.chan_tx * A.vec;
+    const int ra = max(c.y0 - c.pad, 0), rb = min(c.y0 + c.TH - 1 + c.pad, g.H - 1);
+    bad = handoff_wait(A.c.sync + A.bflag0 + static_cast<size_t>(c.b) * A.nflag, (ra * g.W) / TP, ((rb + 1) * g.W - 1) / TP, gen,
+                       A.c.sync + static_cast<size_t>(g.B) * A.nflag, A.spin_limit);
+    if (tid == 0) __hip_atomic_fetch_add(own, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   stage_window<8>(tg, 4, c.PH, c.PW, c.y0 - c.pad, c.x0 - c.pad, g,
-                   [&](int p, int off) { return p == 0 ? gpre[off] : pl[static_cast<size_t>(p - 1) * g.HW + off]; });
+                   [&](int p, int off) { return p == 0 ? (COH ? ld_agent(gpre + off) : gpre[off]) : pl[static_cast<size_t>(p - 1) * g.HW + off]; });
   __syncthreads();
   constexpr int KK = K ? K : 1;
   const int nout = 3 * k * k;
@@ -303,6 +321,7 @@ __device__ __forceinline__ void bwd_wsa_body(const BwdArgs& A, const int local, 
       const int pi = o / KK, j = o - pi * KK;
       float sum = 0.f;
       for (int r = 0; r < c.TH; ++r) sum += accs[(pi * c.TH + r) * KK + j];
+      if (COH && bad) sum = __builtin_nanf("");
       if (AGENT) st_agent(A.s.gwsa_part + static_cast<size_t>(o) * A.nwsa + local, sum);
       else A.s.gwsa_part[static_cast<size_t>(o) * A.nwsa + local] = sum;
     }
@@ -332,7 +351,28 @@ __global__ __launch_bounds__(kBlock) void k_bwd_wsa(const Group<BwdArgs> G) {
 // ---------------------------------------------------------------------------------------------
 // k_bwd_reduce2     (thread layout of k_pool: rows of TX lanes sweep H*W for CPT channels each)
 // ---------------------------------------------------------------------------------------------
-template <typename T, int VEC, int CPT>
+// 16-byte loads that bypass this CU's L1 (sc1: the pair of common.cuh's st_agent for vectors), for data published inside the launch:
+// a raw buffer load with the sc1 bit, tracked by the compiler like any other load.  rsrc: wave-uniform base, byte offsets per lane.
+// (ROCm 7.2's clang narrows the b128 builtin to ONE dword splatted over the vector when its elements are extracted with a loop index
+//  -- seen in the .s and on the device -- so the vector is bit-cast whole and its members are named)
+typedef unsigned int v4u32_t __attribute__((ext_vector_type(4)));
+typedef float v4f32_t __attribute__((ext_vector_type(4)));
+template <int VEC>
+__device__ __forceinline__ void load_plane_agent(__amdgpu_buffer_rsrc_t rsrc, const int elem, float (&out)[VEC]) {
+  if constexpr (VEC % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) {
+      const v4u32_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (elem + 4 * q) * 4, 0, 16);
+      const v4f32_t f = __builtin_bit_cast(v4f32_t, v);
+      out[4 * q] = f.x; out[4 * q + 1] = f.y; out[4 * q + 2] = f.z; out[4 * q + 3] = f.w;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) out[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (elem + e) * 4, 0, 16));
+  }
+}
+
+template <typename T, int VEC, int CPT, bool COH = false>   // COH: g_planes and the tile partials are published inside this launch (k_bwd_r12)
 __device__ __forceinline__ void bwd_reduce2_body(const BwdArgs& A, const int bid, float* red) {
   const Geo& g = A.g;
   const int tid = threadIdx.x;
@@ -359,6 +399,17 @@ __device__ __forceinline__ void bwd_reduce2_body(const BwdArgs& A, const int bid
   float acc[CPT];
 #pragma unroll
   for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
+  bool bad = false;
+  __amdgpu_buffer_rsrc_t gprs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gp0), 0, 2 * g.HW * 4, 0x00020000);
+  if (COH) {
+    // this sample's transposed-conv tiles (lower workgroup ids of this launch) publish g_planes; they in turn waited for the sample's
+    // k_bwd_reduce1 tiles, so the tile partials read below are out as well.  Own generation counter, bounded wait, NaN on time-out.
+    int* own = A.c.sync + A.sflag0 + static_cast<size_t>(b) * g.C + cg;
+    const int gen = static_cast<int>(static_cast<unsigned>(ld_agent(own)) + 1u);
+    const int cps = A.nconv / g.B;                                // conv tiles per sample (sample-major ids)
+    bad = handoff_wait(A.c.sync + A.cflag0, b * cps, b * cps + cps - 1, gen, A.c.sync + static_cast<size_t>(g.B) * A.nflag, A.spin_limit);
+    if (tid == 0) __hip_atomic_fetch_add(own, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 
   constexpr int PF = MGACBAM_POOL_PF;                         // positions per lane per memory round (see k_pool)
   for (int i0 = tx; i0 < nv; i0 += TX * PF) {
@@ -370,8 +421,13 @@ __device__ __forceinline__ void bwd_reduce2_body(const BwdArgs& A, const int bid
       const int i = i0 + p * TX;
       ok[p] = i < nv;
       const size_t o = static_cast<size_t>(ok[p] ? i : nv - 1) * VEC;
-      load_vec<float, VEC>(gp0 + o, g0[p]);
-      load_vec<float, VEC>(gp1 + o, g1[p]);
+      if (COH) {
+        load_plane_agent<VEC>(gprs, static_cast<int>(o), g0[p]);
+        load_plane_agent<VEC>(gprs, g.HW + static_cast<int>(o), g1[p]);
+      } else {
+        load_vec<float, VEC>(gp0 + o, g0[p]);
+        load_vec<float, VEC>(gp1 + o, g1[p]);
+      }
       load_ivec<VEC>(cidx + o, ci[p]);
 #pragma unroll
       for (int j = 0; j < CPT; ++j) load_vec<T, VEC>(xr[j] + o, xv[p][j]);
@@ -395,7 +451,8 @@ __device__ __forceinline__ void bwd_reduce2_body(const BwdArgs& A, const int bid
   for (int j = 0; j < CPT; ++j) {
     const float* part = A.s.A_part + static_cast<size_t>(b) * A.nt * 2 * g.C + cj[j];
     float As = 0.f, Qs = 0.f;
-    for (int t = tx; t < A.nt; t += TX) { As += part[static_cast<size_t>(t) * 2 * g.C]; Qs += part[static_cast<size_t>(t) * 2 * g.C + g.C]; }
+    if (COH) { for (int t = tx; t < A.nt; t += TX) { As += ld_agent(part + static_cast<size_t>(t) * 2 * g.C); Qs += ld_agent(part + static_cast<size_t>(t) * 2 * g.C + g.C); } }
+    else { for (int t = tx; t < A.nt; t += TX) { As += part[static_cast<size_t>(t) * 2 * g.C]; Qs += part[static_cast<size_t>(t) * 2 * g.C + g.C]; } }
     sums[j] = acc[j]; sums[CPT + j] = As; sums[2 * CPT + j] = Qs;
   }
   row_sum<3 * CPT>(sums, TX, tid, red);
@@ -412,7 +469,7 @@ __device__ __forceinline__ void bwd_reduce2_body(const BwdArgs& A, const int bid
         const float As = sums[CPT + j], Qs = sums[2 * CPT + j];
         const float ca = A.c.ca[o];
         const float gca = a * As + sums[j];
-        gzv[j] = gca * ca * (1.f - ca);
+        gzv[j] = (COH && bad) ? __builtin_nanf("") : gca * ca * (1.f - ca);   // NaN: a hand-off that timed out must be loud
         A.s.gz[o] = gzv[j];
         A.s.gbq[o] = Qs;                                       // sum_hw gy*(v - x) for this (b,c)
       }
@@ -473,6 +530,46 @@ __global__ __launch_bounds__(kBlock) BWD_OCC void k_bwd_reduce2(const Group<BwdA
   }
   TRACE_MARK(A.trace, blockIdx.x, 0);
   bwd_reduce2_body<T, VEC, CPT>(A, local, smem);
+#ifdef MGACBAM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TRACE_MARK(A.trace, blockIdx.x, 10);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_bwd_r12: k_bwd_reduce1 tiles, transposed-conv tiles, dWsa tiles and k_bwd_reduce2 sweeps as ONE launch (spatial kernel 7, whole
+//   backward in one call on a zero-filled ctx.sync).  Workgroup ids are PHASE-major over the levels of the group --
+//   [all tiles][all conv tiles][all dWsa tiles][all sweeps] -- and every wait points at lower ids only: conv and dWsa tiles wait for the
+//   k_bwd_reduce1 tiles whose rows they read (generation counters, as in k_bwd_reduce1_fold), a sweep waits for the conv tiles of its
+//   sample.  Producers never wait on higher ids, so progress does not depend on residency; every wait is bounded and poisons on
+//   time-out.  What the merge buys is the boundary between the two launches and their ramp / tail: the sweeps of the first samples
+//   start while the last tiles still stream.  All four bodies fit 64 VGPRs (occupancy 7-8): k_bwd_apply (104) stays a launch of its own
+//   -- capped at its 4 waves per SIMD these two kernels lose 9 us at config 2.
+//   The merged launch has generation counters of its own for every class (args.cuh): the fold form may run on the same ctx in between.
+// ---------------------------------------------------------------------------------------------
+struct R12Group {
+  Group<BwdArgs> g;
+  int seg[4][kGroupMax + 1];     // seg[p][l]: first workgroup id of level l in phase p; seg[p][n]: end of phase p
+};
+template <typename T, int VEC, int CPT>
+__global__ __launch_bounds__(kBlock) BWD_OCC void k_bwd_r12(const R12Group R) {
+  extern __shared__ __align__(16) float smem[];
+  const int bid = blockIdx.x;
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < 4; ++q)
+    if (bid >= R.seg[q][0]) p = q;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < kGroupMax; ++i)
+    if (i < R.g.n && bid >= R.seg[p][i]) l = i;
+  const int local = bid - R.seg[p][l];
+  const BwdArgs& A = R.g.lv[l];
+  if (p == 0) { bwd_reduce1_body<T, VEC, true>(A, local, smem); return; }
+  if (p == 1) { if (local < A.nconv) bwd_convT_body<7, true>(A, local, smem); return; }
+  if (p == 2) { if (local < A.nwsa) bwd_wsa_body<7, false, true>(A, local, smem); return; }
+  TRACE_MARK(A.trace, blockIdx.x, 0);
+  bwd_reduce2_body<T, VEC, CPT, true>(A, local, smem);
 #ifdef MGACBAM_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   TRACE_MARK(A.trace, blockIdx.x, 10);

@@ -79,7 +79,11 @@ static void ctx_layout(int B, int C, int H, int W, int hidden, mgacbam_ctx_layou
   L->cidx = take(static_cast<size_t>(B) * HW);
   L->sa = take(static_cast<size_t>(B) * HW);
   L->proj = take(hidden <= MGACBAM_PROJ_MAX_HIDDEN ? static_cast<size_t>(B) * hidden * HW : 0);
-  L->sync = take(3 * static_cast<size_t>(B) * sync_flags(HW) + 4 + B);
+  // hand-off state: [B][nflag] k_gate tile flags, 4 status words, [B] ca flags, [B][nflag] k_bwd_reduce1 tile flags, [B][nflag] folded
+  // conv-tile flags; merged backward launch (k_bwd_r12): [B][nflag] tile, [B][nflag] conv-tile, [B][nflag] dWsa-tile and [B][C] sweep flags
+  // (the merged launch has tile / conv-tile flags of its OWN beside its dWsa-tile and sweep flags: every class of generation counters is
+  //  bumped exactly once per launch of its kind, so the two launch forms can alternate on one ctx without their counters drifting apart)
+  L->sync = take(6 * static_cast<size_t>(B) * sync_flags(HW) + 4 + B + static_cast<size_t>(B) * C);
   L->status = L->sync + static_cast<int64_t>(4 * static_cast<size_t>(B) * sync_flags(HW));   // status word 0 (time-out) follows the k_gate tile flags
   L->total = static_cast<int64_t>(o);
 }
@@ -112,6 +116,7 @@ static int env_int(const char* name, int dflt) {
 // Tuning / test knobs come from the environment ONCE (first call) -- not per call: the eager path makes ~50 look-ups per step
 // otherwise.  mgacbam_reload_env() re-reads them (tests and tuning sweeps that change the environment in-process).
 struct Knobs {
+  int bwd_merge;           // MGACBAM_BWD_MERGE (default 1): k_bwd_reduce1 + conv + dWsa tiles + k_bwd_reduce2 as one launch (k_bwd_r12)
   int wsa_tail;            // MGACBAM_WSA_TAIL (default 0, opt-in): dWsa tile partials + sums as the last workgroups of the k_bwd_apply launch
   int gate_narrow;         // MGACBAM_GATE_NARROW (default 0): k_gate also for tiles narrower than an image row
   int gate, chan_mintx, pool_tx, pool_cpt, r2_cpt, wsa_fat, chan_tx, chanf_tx, split_mlp, nt, half_vec, gate_h8, level_order, bwd_fold;
@@ -122,6 +127,7 @@ struct Knobs {
 };
 static Knobs read_knobs() {
   Knobs k;
+  k.bwd_merge = env_int("MGACBAM_BWD_MERGE", 1);
   k.wsa_tail = env_int("MGACBAM_WSA_TAIL", 0);
   k.gate_narrow = env_int("MGACBAM_GATE_NARROW", 0);
   k.gate = env_int("MGACBAM_GATE", 1); k.chan_mintx = env_int("MGACBAM_CHAN_MINTX", 16);

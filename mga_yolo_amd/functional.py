@@ -350,8 +350,9 @@ def ctx_views(cbuf: torch.Tensor, B, Cc, H, W, hidden) -> dict:
     if hidden <= _lib.PROJ_MAX_HIDDEN:
         shapes["proj"] = (B, hidden, HW)
     nflag = (HW + 15) // 16 + 1
-    # hand-off state: (B, nflag) k_gate flags, [time-out status, 3 spare], (B) ca flags, (B, nflag) BWD_FOLD tile flags, (B, nflag) conv-tile flags
-    shapes["sync"] = (3 * B * nflag + 4 + B,)
+    # hand-off state: (B, nflag) k_gate flags, [time-out status, 3 spare], (B) ca flags, (B, nflag) BWD_FOLD tile flags, (B, nflag) conv-tile flags,
+    # then the merged backward launch's own (B, nflag) tile, conv-tile and dWsa-tile flags and (B, C) sweep flags
+    shapes["sync"] = (6 * B * nflag + 4 + B + B * Cc,)
     ints = {"valid", "amax", "cidx", "sync"}
     out = {}
     for name, shp in shapes.items():

@@ -69,7 +69,7 @@ def test_ctx_layout_is_packed_aligned_and_ordered(built_lib, shape):
     assert lay["status"] == lay["sync"] + 4 * B * ((H * W + 15) // 16 + 1)      # the time-out word follows the k_gate tile flags
     sizes = dict(S=B, use=B, den=B, avg=B * Cc, mx=B * Cc, mavg=B * Cc, valid=B * Cc, amax=B * Cc, h_avg=B * hid, h_mx=B * hid,
                  ca=B * Cc, planes=B * 3 * H * W, cidx=B * H * W, sa=B * H * W,
-                 proj=B * hid * H * W if hid <= _lib.PROJ_MAX_HIDDEN else 0, sync=3 * B * ((H * W + 15) // 16 + 1) + 4 + B)
+                 proj=B * hid * H * W if hid <= _lib.PROJ_MAX_HIDDEN else 0, sync=6 * B * ((H * W + 15) // 16 + 1) + 4 + B + B * Cc)
     prev_end = 0
     for n in order:
         assert lay[n] % 16 == 0 and lay[n] >= prev_end, n

@@ -753,9 +753,57 @@ def test_fold_counters_survive_a_half_finished_backward(F):
     for l, (Bn, C, H, W) in enumerate(plan.shapes):
         nf = Bn * ((H * W + 15) // 16 + 1)
         sync = plan.ctx_view(l)["sync"]
-        tiles, convs = sync[nf + 4 + Bn:nf + 4 + Bn + nf], sync[nf + 4 + Bn + nf:]
-        assert set(tiles.unique().tolist()) <= {0, 5} and int(tiles.max()) == 5      # fold_active's launch + 3 + 1 folded launches
-        assert set(convs.unique().tolist()) <= {0, 5} and int(convs.max()) == 5
+        o = nf + 4 + Bn
+        tiles, convs = sync[o:o + nf], sync[o + nf:o + 2 * nf]
+        assert set(tiles.unique().tolist()) <= {0, 4} and int(tiles.max()) == 4      # fold_active's launch + 3 folded launches
+        assert set(convs.unique().tolist()) <= {0, 4} and int(convs.max()) == 4
+        # the full backward ran as the MERGED launch (k_bwd_r12), which counts in generation counters of its own -- one class per kind
+        # of workgroup, each bumped exactly once per merged launch -- so the two launch forms can alternate on one ctx
+        for name, blk in (("tiles", sync[o + 2 * nf:o + 3 * nf]), ("conv tiles", sync[o + 3 * nf:o + 4 * nf]),
+                          ("dWsa tiles", sync[o + 4 * nf:o + 5 * nf]), ("sweeps", sync[o + 5 * nf:])):
+            assert set(blk.unique().tolist()) <= {0, 1} and int(blk.max()) == 1, (l, name)
+    plan.forward(); plan.backward()                       # and once more: merged generation 2 next to fold generation 4
+    ref.forward(); ref.backward()
+    plan.check_handoff()
+    for a, b in zip(plan.gx + plan.gmask + [plan.grad_bucket], ref.gx + ref.gmask + [ref.grad_bucket]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shapes", [[(32, 64, 80, 80), (32, 128, 40, 40), (32, 256, 20, 20)], [(5, 48, 24, 40), (3, 96, 12, 20)]])
+def test_merged_backward_launch_gives_the_same_bits(F, shapes, monkeypatch):
+    """k_bwd_r12 (k_bwd_reduce1 tiles + transposed-conv tiles + dWsa tiles + k_bwd_reduce2 sweeps in ONE launch, in-launch hand-offs per
+    sample) against the separate launches (MGACBAM_BWD_MERGE=0): every gradient bit for bit, eager calls and graph replays, status clear."""
+    from mga_yolo_amd import _lib
+    from mga_yolo_amd.plan import PyramidPlan
+    params, cfgs, data = [], [], []
+    for l, (B, C, H, W) in enumerate(shapes):
+        p = O.Params.default_init(C, seed=l)
+        p.beta.fill_(0.25)
+        params.append((p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta)); cfgs.append(F.BlockConfig(hidden=p.w1.shape[0]))
+        data.append(synth(B, C, H, W, seed=80 + l, mask_kind="sparse"))
+
+    def run():
+        plan = PyramidPlan(shapes, params, cfgs)
+        for l, (x, mask, gy) in enumerate(data):
+            plan.x[l].copy_(x); plan.mask[l].copy_(mask); plan.gy[l].copy_(gy)
+        for _ in range(2):
+            plan.forward(); plan.backward()
+        g = plan.capture(lambda: (plan.forward(), plan.backward()))
+        for _ in range(3):
+            g.replay()
+        plan.check_handoff()
+        return plan.grad_bucket.clone(), [t.clone() for t in plan.gx], [t.clone() for t in plan.gmask]
+
+    merged = run()
+    monkeypatch.setenv("MGACBAM_BWD_MERGE", "0")
+    _lib.reload_env()
+    try:
+        split = run()
+    finally:
+        monkeypatch.undo()
+        _lib.reload_env()
+    assert torch.equal(merged[0], split[0])
+    assert all(torch.equal(a, b) for a, b in zip(merged[1] + merged[2], split[1] + split[2]))
 
 
 def test_stale_scratch_size_after_a_knob_change_raises_instead_of_faulting(F, monkeypatch):

@@ -18,6 +18,8 @@ stages = [("fwd.pool", plan.forward, Fs["pool"], 1)]
 stages += [("fwd.gate", plan.forward, Fs["chan"] | Fs["apply"], 2)] if gate else [("fwd.chan", plan.forward, Fs["chan"], 1), ("fwd.apply", plan.forward, Fs["apply"], 2)]
 stages += [("bwd.reduce1+convT(fold)", plan.backward, Bs["reduce1"] | Bs["convT"] | _lib.BWD_FOLD, 2)] if fold else \
           [("bwd.reduce1", plan.backward, Bs["reduce1"], 2), ("bwd.convT", plan.backward, Bs["convT"], 0)]
+if fold:
+    stages += [("bwd.r12 (merged launch)", plan.backward, Bs["reduce1"] | Bs["convT"] | Bs["reduce2"] | Bs["wsa"] | _lib.BWD_FUSE | _lib.BWD_FOLD, 3)]
 stages += [("bwd.reduce2+wsa", plan.backward, Bs["reduce2"] | Bs["wsa"] | _lib.BWD_FUSE, 1),
            ("bwd.reduce2 only", plan.backward, Bs["reduce2"], 1),
            ("bwd.apply+params", plan.backward, Bs["params"] | Bs["apply"] | _lib.BWD_FUSE, 3),
