@@ -11,12 +11,12 @@ static int head_check_shape(int B, int C, int H, int W, int hidden) {
   if (static_cast<long long>(H) * W > (1ll << 28) || static_cast<long long>(B) * std::max(C, hidden) * H * W > (1ll << 40))
     return fail(MGACBAM_E_SHAPE, "mask head: tensor too large B=%d C=%d H=%d W=%d", B, C, H, W);
   // the 3x3 kernels stage runs of pixels with a halo of W+1 either side in LDS: rows wider than the budget are refused here, not at launch
-  { int opx, ojo; head_out_shape(hidden, W, opx, ojo);
-    if (ojo < 1 || (static_cast<size_t>(kBlock) * 4 + 2 * (static_cast<size_t>(W) + 1) + 16 * kHeadJC * kHeadNStat) * sizeof(float) > 60 * 1024)
-      return fail(MGACBAM_E_SHAPE, "mask head: image rows of W=%d do not fit the 3x3 kernels' LDS staging (W <= ~1390)", W); }
+  { int ppt, opx, per;
+    if (!head_out_shape(hidden, H * W, W, ppt, opx, per) || (static_cast<size_t>(kBlock) * 4 + 2 * (static_cast<size_t>(W) + 1) + 16 * kHeadJC * kHeadNStat) * sizeof(float) > 60 * 1024)
+      return fail(MGACBAM_E_SHAPE, "mask head: image rows of W=%d do not fit the 3x3 kernels' pixel runs (W <= 500)", W); }
   return 0;
 }
-struct HeadTiling { int vec, hidp, cp, tile_px, tps, nwg, gx_tile_px, gx_tps, fw_kw, gx_kw, fw_mtw, gx_mtw, nwg_out, nwg1, act_ppt, act_hl, ncb, nshare, gw2; };
+struct HeadTiling { int vec, hidp, cp, tile_px, tps, nwg, gx_tile_px, gx_tps, fw_kw, gx_kw, fw_mtw, gx_mtw, nwg_out, out_ppt, out_px, out_per, nwg1, act_ppt, act_hl, ncb, nshare, gw2; };
 // wave arrangement of k_head_gemm (head.cuh): MW waves along M for `mtiles` 16-output tiles, KW waves along K when K is long (a chain of
 // K/4 dependent steps otherwise), the rest along pixels
 static void head_waves(int mtiles, int mtw, int K, int& pw, int& kw) {
@@ -41,7 +41,8 @@ static HeadTiling head_tiling(int B, int C, int H, int W, int hidden) {
   head_waves(t.cp / 16, t.gx_mtw, hidden, pw, t.gx_kw);
   t.gx_tile_px = pw * 16 * t.vec;
   t.gx_tps = (HW + t.gx_tile_px - 1) / t.gx_tile_px;
-  { int opx, ojo; head_out_shape(hidden, W, opx, ojo); t.nwg_out = B * ((HW + opx - 1) / opx); }
+  head_out_shape(hidden, HW, W, t.out_ppt, t.out_px, t.out_per);
+  t.nwg_out = B * t.out_per;
   t.act_ppt = HW >= 2048 ? 4 : (HW >= 512 ? 2 : 1);             // pixels per thread of k_head_bwd_act (amortises its per-channel reductions)
   t.nwg1 = B * ((HW + kBlock * t.act_ppt - 1) / (kBlock * t.act_ppt));
   t.act_hl = kBlock * t.act_ppt + 2 * (W + 1);
@@ -112,7 +113,7 @@ static int head_common(const mgahead_params_t& P, int B, int C, int H, int W, in
   A.tile_px = t.tile_px; A.tiles_per_sample = t.tps; A.nwg = t.nwg;
   A.gx_tile_px = t.gx_tile_px; A.gx_tiles_per_sample = t.gx_tps; A.fw_kw = t.fw_kw; A.gx_kw = t.gx_kw; A.fw_mtw = t.fw_mtw; A.gx_mtw = t.gx_mtw;
   A.trace = knobs().trace; A.trace_base = 0;
-  A.nwg_out = t.nwg_out; A.nwg1 = t.nwg1; A.act_ppt = t.act_ppt; A.act_hl_max = t.act_hl; A.ncb = t.ncb; A.nshare = t.nshare; A.gw2 = t.gw2;
+  A.nwg_out = t.nwg_out; A.out_ppt = t.out_ppt; A.out_px = t.out_px; A.out_per = t.out_per; A.nwg1 = t.nwg1; A.act_ppt = t.act_ppt; A.act_hl_max = t.act_hl; A.ncb = t.ncb; A.nshare = t.nshare; A.gw2 = t.gw2;
   sig = Sig{dtype, t.vec, 0, 0, 0, 0};
   return 0;
 }
@@ -169,15 +170,8 @@ static int head_forward_group(HeadArgs* lv, int n, const Sig& sig, hipStream_t s
     if (int e = launch_status("k_head_stats")) return e;
   }
   {
-    int ohl = 0;                                                  // LDS floats per wave: the level's rows and constants
-    for (int l = 0; l < n; ++l) {
-      int opx, ojo;
-      head_out_shape(lv[l].g.hid, lv[l].g.W, opx, ojo);
-      ohl = std::max(ohl, ojo * (head_out_row(opx, lv[l].g.W) + kHeadOutCst));
-    }
-    for (int l = 0; l < n; ++l) { lv[l].out_hl_max = ohl; G.lv[l].out_hl_max = ohl; }
     const int grid = head_fill(G, lv, n, [](const HeadArgs& a) { return a.nwg_out; });
-    const size_t smem = std::max(static_cast<size_t>(4) * ohl, static_cast<size_t>(16) * kWave) * sizeof(float);
+    const size_t smem = 0;
 #define CALL_HO(Tt) { if (sig.vec == 4) { LAUNCH((k_head_out<Tt, 4>), grid, smem, st, G); } else { LAUNCH((k_head_out<Tt, 1>), grid, smem, st, G); } }
     switch (sig.lf32 ? MGACBAM_F32 : sig.dtype) {              // (the kernel's element type is the LOGITS' type: z is fp32)
       case MGACBAM_F32: CALL_HO(float); break;

@@ -122,6 +122,14 @@ __device__ __forceinline__ float dpp_add(float v) {
 __device__ __forceinline__ float uniform_load(const float* p) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *p)));
 }
+// a wave-uniform pointer, pinned in scalar registers: address = SGPR base + a lane's 32-bit byte offset is then ONE VGPR per load (left
+// alone the compiler folds the lane's part into the base first and keeps a 64-bit VGPR address per row: 2 registers per load in flight)
+template <typename P>
+__device__ __forceinline__ const P* uniform_ptr(const P* p) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(u)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(u >> 32));
+  return reinterpret_cast<const P*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
 __device__ __forceinline__ float wave_group_sum(float v, int width) {
   if (width >= 2) v = dpp_add<0xB1>(v);                         // quad_perm [1,0,3,2]
   if (width >= 4) v = dpp_add<0x4E>(v);                         // quad_perm [2,3,0,1]

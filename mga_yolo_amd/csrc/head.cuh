@@ -23,6 +23,7 @@
 namespace mgacbam {
 
 typedef float v4f32 __attribute__((ext_vector_type(4)));
+typedef float v2f32 __attribute__((ext_vector_type(2)));
 typedef short v4i16 __attribute__((ext_vector_type(4)));
 typedef _Float16 v4f16 __attribute__((ext_vector_type(4)));
 typedef __bf16 v4bf16 __attribute__((ext_vector_type(4)));
@@ -88,7 +89,7 @@ struct HeadArgs {
   int gx_tile_px, gx_tiles_per_sample;         // ... of k_head_gemm<GX>
   int fw_kw, gx_kw;                            // waves of a workgroup that split the K steps (1, 2, 4)
   int fw_mtw, gx_mtw;                          // M tiles per wave (template parameter of the launch the level rides in)
-  int nwg_out, out_hl_max;                     // k_head_out: workgroups (runs of out_px pixels), LDS floats per WAVE (launch maximum: rows + constants)
+  int nwg_out, out_ppt, out_px, out_per;       // k_head_out: workgroups, staged pixels per thread, outputs per workgroup, workgroups per sample
   int nwg1, act_ppt, act_hl_max;               // k_head_bwd_act: pixel runs of the level, pixels per thread, LDS floats of the launch's longest run
   int ncb, nshare, gw2;                        // k_head_bwd_gw[2]: channel blocks, pixel shares per block (= partial sets of dW1), LDS-staged form
   long long* trace;                            // MGACBAM_TRACE builds only (tools/trace_head.py), else nullptr
@@ -496,172 +497,182 @@ __global__ __launch_bounds__(kBlock) void k_head_stats(const Group<HeadArgs> G) 
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_head_out: logits = conv3x3(SiLU(gamma * zhat + beta)) + bias                                  segmentation.py:83-92
-//   workgroup = a run of out_px consecutive pixels of one sample (H*W flattened: full lanes whatever the image shape); its 4 waves
-//   cover the SAME pixels (lane = out_px / 64 consecutive ones) and split the hidden channels 4 ways; the four partial sums meet in LDS.
-//   The run length follows the channel count so that a wave stages ALL its channels in one pass at the same LDS budget -- 256 pixels
-//   x 4 channels per wave (hidden <= 16), 128 x 8 (<= 32), 64 x 16 (<= 64; more channels: passes of 16): with 256-pixel runs for
-//   every level the levels with many channels were 2-4 dependent passes deep and set the launch's duration.  A wave stages the
-//   activations of its channels over the run plus W+1 pixels either side (zero outside the sample = the conv's zero padding in y) in
-//   its own LDS rows (no workgroup barrier), reads ppl + 2 consecutive values per channel and window row for its ppl outputs and masks
-//   the taps that would wrap around a row end (padding in x).  3x3 weights and BatchNorm constants: from the per-channel table into
-//   the wave's LDS once per pass, read back as broadcasts.
+//   The 3x3 conv over `hidden` channels is linear in the taps:  logits[p] = sum_{u,v} t_uv[p + (u-1) W + (v-1)]  with the PER-PIXEL sums
+//   t_uv[q] = sum_c W_h[c][u][v] * s_c[q]  -- nine numbers per pixel that need no neighbour.  So the activations never visit LDS: a thread
+//   owns PPT consecutive staged pixels, loads ALL hidden channels of them straight into registers (16- / 8- / 4-byte loads, every one
+//   requested before the first is used at the YOLOv8 widths: one memory round trip per workgroup) and accumulates 9 x PPT tap sums;
+//   only the nine-plane shift-sum goes through LDS, in two steps: the horizontal one (a thread needs one tap of each neighbour: 6 values
+//   per thread) gives h_u[r] = [x>0] t_u0[r-1] + t_u1[r] + [x<W-1] t_u2[r+1], the vertical one logits[p] = h_0[p-W] + h_1[p] + h_2[p+W]
+//   (two planes of the run in LDS, 8 KB).  Workgroup = a run of 256 x PPT staged pixels of one sample = its outputs plus W+1 pixels either
+//   side (zero outside the sample = the conv's padding in y; taps that would wrap a row end are the [x..] factors = padding in x).
+//   PPT = 4 / 2 / 1 for hidden <= 16 / 32 / more, so every workgroup of a YOLOv8 pyramid carries the same 64 values per thread; rows so
+//   wide that the halo eats the run take the next PPT.  (Round 2's form staged the ACTIVATIONS of a run in LDS, hidden/4 channels per
+//   wave: 32 KB per workgroup, 1.6x halo overhead, 1,440 workgroups in two resident rounds of ~11 us each at config 2 -- 20.7 us for 23 MB.)
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int kHeadOutPxMax = 256;
-constexpr int kHeadOutCst = 12;                                 // LDS floats per channel of constants: scale, shift, 9 weights (+1 pad)
-// run length / channels per wave and pass of a level, and the LDS row of one staged channel: the run, W+1 pixels either side and the
-// slack of starting on a 16-byte boundary
-__host__ __device__ inline int head_out_row(int out_px, int W) { return (out_px + 2 * (W + 1) + 3 + 3) & ~3; }
-constexpr int kHeadOutLds = 48 * 1024;                          // LDS budget of a k_head_out workgroup (4 waves x jo rows + constants)
-__host__ __device__ inline size_t head_out_lds(int out_px, int jo, int W) {
-  return static_cast<size_t>(4) * jo * (head_out_row(out_px, W) + kHeadOutCst) * sizeof(float);
+constexpr int kHeadOutParCh = 128;                             // channels whose constants are staged in LDS at a time
+__host__ __device__ inline int head_out_max(int ppt, int W) { return (kBlock * ppt - 2 * (W + 1) - 3) & ~3; }   // outputs a run can hold (3: the run starts on a 16-byte boundary)
+// pixels per thread, outputs per workgroup (a multiple of 4) and workgroups per sample of a level; false: rows too wide (W > ~500)
+__host__ __device__ inline bool head_out_shape(int hid, int HW, int W, int& ppt, int& opx, int& per) {
+  ppt = hid <= 16 ? 4 : (hid <= 32 ? 2 : 1);
+  while (ppt < 4 && head_out_max(ppt, W) < 64) ppt *= 2;
+  const int mo = head_out_max(ppt, W);
+  if (mo < 4) return false;
+  per = (HW + mo - 1) / mo;
+  opx = ((HW + per - 1) / per + 3) & ~3;
+  return true;
 }
-// Wide images (W >= ~100 at hidden > 32: 1280-px inputs at m/l/x widths) would not fit the budget with the run length picked from the
-// channel count alone -- the halo of W+1 pixels either side dominates a short run: they take the longest run and fewer channels per pass
-// (more passes instead of a launch failure).  jo = 0: even one channel per pass does not fit (W > ~1390): the caller reports E_SHAPE.
-__host__ __device__ inline void head_out_shape(int hid, int W, int& out_px, int& jo) {
-  const int cw = (hid + 3) >> 2;
-  if (cw <= 4) { out_px = 256; jo = 4; } else if (cw <= 8) { out_px = 128; jo = 8; } else { out_px = 64; jo = 16; }
-  if (head_out_lds(out_px, jo, W) <= kHeadOutLds) return;
-  out_px = 256;
-  for (jo = 4; jo >= 1 && head_out_lds(out_px, jo, W) > kHeadOutLds; jo >>= 1) {}
-}
-template <typename T, int VEC>
-__device__ __forceinline__ void head_out_body(const HeadArgs& A, const int wg, float* smem) {
+template <typename T, int VEC, int PPT>
+__device__ __forceinline__ void head_out_run(const HeadArgs& A, const int wg, float* s_par, float* s_ex, float* s_h) {
   const HeadGeo& g = A.g;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  int out_px, jo;
-  head_out_shape(g.hid, g.W, out_px, jo);
-  const int ppl = out_px >> 6;                                  // pixels per lane: 4, 2, 1
-  const int per = (g.HW + out_px - 1) / out_px;
-  const int b = wg / per, p0 = (wg - b * per) * out_px;
-  const int halo = g.W + 1;
-  const int lo = VEC == 4 ? ((p0 - halo) & ~3) : p0 - halo;     // first staged pixel (may be negative); VEC = 4: H*W % 4 == 0, every 16-byte group is wholly inside or outside the sample
-  const int nel = (p0 + out_px + halo - lo + VEC - 1) / VEC;    // VEC-groups staged per channel
-  const int NQ = (nel + kWave - 1) / kWave;                     // ... per lane
-  const int HLs = head_out_row(out_px, g.W);                    // row stride in LDS
-  const int pt = p0 + ppl * lane;                               // this lane's first pixel
-  float ml[4], mr[4];                                           // 0 where the left / right tap would wrap around the row end
+  const int tid = threadIdx.x;
+  constexpr int SLOTS = kBlock * PPT;
+  constexpr int CB = 32 / PPT;                                  // channels per batch: 32 values per thread; two batches are requested ahead
+  const int per = A.out_per, opx = A.out_px;
+  const int b = wg / per, p0 = (wg - b * per) * opx, pend = min(p0 + opx, g.HW);
+  int lo = p0 - (g.W + 1);
+  if (VEC == 4) lo &= ~3;                                       // H*W % 4 == 0: every aligned group of PPT pixels is wholly inside or outside the sample
+  const int s0 = lo + tid * PPT;                                // this thread's first staged pixel (index in the sample; may lie outside it)
+  bool ins[PPT];
+  unsigned keep[PPT];
+  float ml[PPT], mr[PPT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int x = (pt + i) % g.W;
+  for (int i = 0; i < PPT; ++i) {
+    ins[i] = s0 + i >= 0 && s0 + i < g.HW;
+    keep[i] = ins[i] ? 0xffffffffu : 0u;
+    const int x = (s0 + i + 8 * g.W) % g.W;                     // (s0 >= -(W + 4))
     ml[i] = x > 0 ? 1.f : 0.f; mr[i] = x < g.W - 1 ? 1.f : 0.f;
   }
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
   const int gid = 24576 + blockIdx.x;
   TRACE_HWID(A.trace, gid);
   TRACE_MARK(A.trace, gid, 0);
   const float* zb = A.c.z + static_cast<size_t>(b) * g.hid * g.HW;
-  float* s_w = smem + static_cast<size_t>(wave) * A.out_hl_max;  // this wave's staging area ([jo][HLs] rows, then [jo][12] constants): written and read by this wave only
-  float* s_c = s_w + jo * HLs;
-  const int cw = (g.hid + 3) >> 2;                              // channels per wave
-  const int jlo = wave * cw, jhi = min(g.hid, jlo + cw);
-  const int npass = (cw + jo - 1) / jo;
-  for (int ps = 0; ps < npass; ++ps) {
-    const int j0 = jlo + ps * jo;
-    const int jn = max(0, min(jo, jhi - j0));
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (the previous pass's LDS reads are done before the rows are overwritten)
-    __builtin_amdgcn_wave_barrier();
-    // constants of the pass's channels: one load per lane and value, all in flight beside the activations
-    float cst[3];
+  // every load is unconditional from a valid address (pixels outside the sample: the channel's first group, zeroed where the activation
+  // is formed), as a raw buffer load: descriptor = the sample's z block, scalar offset = the channel row, ONE byte-offset VGPR per lane
+  // for all rows (global loads kept a 64-bit VGPR address per row in flight -- 2 x 64 registers -- and no exec-mask branches either)
+  unsigned so[PPT];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int idx = lane + u * kWave, jj = idx / 11, q = idx - jj * 11;
-      cst[u] = 0.f;
-      if (jj < jn) cst[u] = A.c.par[static_cast<size_t>(j0 + jj) * kHeadPar + (q < 2 ? q : q + 2)];
-    }
-    // stage: batches of QU lane-groups x JU channels = 8 (VEC = 4) loads per lane, all requested before the first is used.  Everything
-    // that varies per lane (pixel, inside-the-sample test, LDS column) belongs to the lane-group, everything per channel is wave-uniform.
-    bool cst_stored = false;
-    auto stage = [&](auto QUc, auto JUc) {
-      constexpr int QU = decltype(QUc)::value, JU = decltype(JUc)::value;
-      for (int q0 = 0; q0 < NQ; q0 += QU) {
-        int idx[QU], pp[QU];
-        bool act[QU], ins[QU];
+  for (int i = 0; i < PPT; ++i) so[i] = ins[i] ? static_cast<unsigned>(s0 + i) * 4u : 0u;
+  const unsigned row_bytes = static_cast<unsigned>(g.HW) * 4u;
+  const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zb), 0, static_cast<int>(row_bytes * static_cast<unsigned>(g.hid)), 0x00020000);
+  auto fetch = [&](const int c0, float (&zv)[CB][PPT]) {
 #pragma unroll
-        for (int qi = 0; qi < QU; ++qi) {
-          idx[qi] = (q0 + qi) * kWave + lane;
-          pp[qi] = lo + idx[qi] * VEC;
-          act[qi] = q0 + qi < NQ && idx[qi] < nel;
-          ins[qi] = pp[qi] >= 0 && pp[qi] < g.HW;              // outside the sample: the conv's zero padding (of the ACTIVATION)
-        }
-        for (int jb = 0; jb < jn; jb += JU) {
-          float zv[QU][JU][VEC];
+    for (int jj = 0; jj < CB; ++jj) {
+      const unsigned ro = static_cast<unsigned>(min(c0 + jj, g.hid - 1)) * row_bytes;   // past the last channel: a valid row, weight 0 below
+      if (VEC == 4 && PPT == 4) {
+        const v4f32 f = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(zrs, so[0], ro, 0));   // (whole-vector cast: see bwd.cuh load_plane_agent)
+        zv[jj][0] = f.x; zv[jj][1] = f.y; zv[jj][2] = f.z; zv[jj][3] = f.w;
+      } else if (VEC == 4 && PPT == 2) {
+        const v2f32 f = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(zrs, so[0], ro, 0));
+        zv[jj][0] = f.x; zv[jj][PPT - 1] = f.y;
+      } else {
 #pragma unroll
-          for (int ji = 0; ji < JU; ++ji) {
-            const float* zr = zb + static_cast<size_t>(j0 + min(jb + ji, jn - 1)) * g.HW;   // uniform
-#pragma unroll
-            for (int qi = 0; qi < QU; ++qi) {
-#pragma unroll
-              for (int r = 0; r < VEC; ++r) zv[qi][ji][r] = 0.f;
-              if (jb + ji < jn && act[qi] && ins[qi]) load_vec<float, VEC>(zr + pp[qi], zv[qi][ji]);
-            }
-          }
-          if (!cst_stored) {                                    // (uniform) the constants arrived with or before the first batch
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-              const int ci = lane + u * kWave, jj = ci / 11, q = ci - jj * 11;
-              if (jj < jn) s_c[jj * kHeadOutCst + q] = cst[u];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            cst_stored = true;
-          }
-#pragma unroll
-          for (int ji = 0; ji < JU; ++ji) {
-            if (jb + ji < jn) {                                 // uniform
-              const float sc = s_c[(jb + ji) * kHeadOutCst], sh = s_c[(jb + ji) * kHeadOutCst + 1];   // uniform address: LDS broadcast
-#pragma unroll
-              for (int qi = 0; qi < QU; ++qi) {
-                if (act[qi]) {
-                  float o[VEC];
-#pragma unroll
-                  for (int r = 0; r < VEC; ++r) o[r] = ins[qi] ? siluf(zv[qi][ji][r] * sc + sh) : 0.f;
-                  store_vec<float, VEC>(s_w + (jb + ji) * HLs + idx[qi] * VEC, o);
-                }
-              }
-            }
-          }
-        }
+        for (int i = 0; i < PPT; ++i) zv[jj][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrs, so[i], ro, 0));
       }
-    };
-    if (NQ == 1) stage(std::integral_constant<int, 1>{}, std::integral_constant<int, VEC == 4 ? 8 : 16>{});
-    else stage(std::integral_constant<int, 2>{}, std::integral_constant<int, VEC == 4 ? 4 : 8>{});
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (ps == 0) TRACE_MARK(A.trace, gid, 1);                    // first pass staged
-    for (int jj = 0; jj < jn; ++jj) {
+    }
+  };
+  float t[9][PPT];
+#pragma unroll
+  for (int q = 0; q < 9; ++q)
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) t[q][i] = 0.f;
+  // constants {scale, shift, W_h[0..8]} of the channels: staged in LDS (chunks of kHeadOutParCh channels), read back as broadcasts two
+  // channels ahead of their use.  That distance is ENFORCED: the LDS offset of channel j + 2 passes through an empty asm that takes a tap
+  // sum of channel j as input.  Left alone the compiler hoists every channel's twelve reads above the arithmetic (400+ registers: one wave
+  // per SIMD); scalar loads from the table instead (SGPR operands) serialise at ~1.4 us per channel under load (measured: 26-90 us).
+  auto accumulate = [&](const int c0, const int ch0, const float (&zv)[CB][PPT]) {
+    unsigned tk[CB + 2];
+    tk[0] = 0u; tk[1] = 0u;
+    asm volatile("" : "+v"(tk[0]), "+v"(tk[1]));
+#pragma unroll
+    for (int jj = 0; jj < CB; ++jj) {
+      const float* pc = s_par + (c0 + jj - ch0) * 12 + tk[jj];   // uniform address: LDS broadcast (weights of channels past the last are 0)
+      const float sc = pc[0], sh = pc[1];
       float w[9];
 #pragma unroll
-      for (int q = 0; q < 9; ++q) w[q] = s_c[jj * kHeadOutCst + 2 + q];
-      const float* a = s_w + jj * HLs + (pt - lo);               // activation of pixel pt
+      for (int q = 0; q < 9; ++q) w[q] = pc[2 + q];
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const float* row = a + (u - 1) * g.W - 1;
-        float s6[6];
+      for (int i = 0; i < PPT; ++i) {
+        // outside the sample: the conv's zero padding (of the ACTIVATION) -- as a bit mask: a select here became a branch per channel
+        const float a = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, siluf(zv[jj][i] * sc + sh)) & keep[i]);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) s6[q] = q < ppl + 2 ? row[q] : 0.f;
+        for (int q = 0; q < 9; ++q) t[q][i] += w[q] * a;
+      }
+      tk[jj + 2] = tk[jj];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (i < ppl) acc[i] += w[u * 3] * (ml[i] * s6[i]) + w[u * 3 + 1] * s6[i + 1] + w[u * 3 + 2] * (mr[i] * s6[i + 2]);
+      for (int i = 0; i < PPT; ++i)                             // (every tap sum: the ones not named here were deferred, their operands parked in registers)
+        asm volatile("" : "+v"(tk[jj + 2]) : "v"(t[0][i]), "v"(t[1][i]), "v"(t[2][i]), "v"(t[3][i]), "v"(t[4][i]), "v"(t[5][i]), "v"(t[6][i]), "v"(t[7][i]), "v"(t[8][i]));
+    }
+  };
+  float z0[CB][PPT], z1[CB][PPT];
+  for (int ch0 = 0; ch0 < g.hid; ch0 += kHeadOutParCh) {
+    // the chunk's constants from the per-channel table, requested before the activations
+    constexpr int NPC = kHeadOutParCh * 12 / kBlock;
+    float pv[NPC];
+#pragma unroll
+    for (int u = 0; u < NPC; ++u) {
+      const int idx = tid + u * kBlock, jj = idx / 12, q = idx - jj * 12;
+      pv[u] = 0.f;
+      if (ch0 + jj < g.hid && q < 11) pv[u] = A.c.par[static_cast<size_t>(ch0 + jj) * kHeadPar + (q < 2 ? q : q + 2)];
+    }
+    if (ch0 == 0) {
+      fetch(0, z0);
+      if (CB < g.hid) fetch(CB, z1);
+    } else {
+      __syncthreads();                                          // the previous chunk's constants have been read
+    }
+#pragma unroll
+    for (int u = 0; u < NPC; ++u) s_par[tid + u * kBlock] = pv[u];
+    __syncthreads();
+    if (ch0 == 0) TRACE_MARK(A.trace, gid, 1);                   // constants staged
+    const int chn = min(g.hid, ch0 + kHeadOutParCh);
+    for (int c0 = ch0; c0 < chn; c0 += 2 * CB) {                // (kHeadOutParCh is a multiple of 2 * CB)
+      accumulate(c0, ch0, z0);
+      if (c0 + 2 * CB < g.hid) fetch(c0 + 2 * CB, z0);
+      if (c0 + CB < g.hid) {
+        accumulate(c0 + CB, ch0, z1);
+        if (c0 + 3 * CB < g.hid) fetch(c0 + 3 * CB, z1);
       }
     }
   }
-  __syncthreads();                                              // the waves' channel shares meet (fixed order)
-  TRACE_MARK(A.trace, gid, 2);                                  // all passes done
-  float* s_acc = smem;
-  if (wave > 0) {
+  TRACE_MARK(A.trace, gid, 2);                                  // tap sums done
+  // horizontal step: t_u0 of the pixel left of the thread's first one, t_u2 of the pixel right of its last one
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s_acc[(wave * 4 + i) * kWave + lane] = acc[i];
+  for (int u = 0; u < 3; ++u) {
+    s_ex[u * kBlock + tid] = t[u * 3][PPT - 1];
+    s_ex[(3 + u) * kBlock + tid] = t[u * 3 + 2][0];
   }
   __syncthreads();
-  if (wave == 0) {
-    const float bias = A.p.bh[0];
-    T* lo_ = static_cast<T*>(A.logits) + static_cast<size_t>(b) * g.HW;
+  float h[3][PPT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float v = ((acc[i] + s_acc[(4 + i) * kWave + lane]) + (s_acc[(8 + i) * kWave + lane] + s_acc[(12 + i) * kWave + lane])) + bias;
-      if (i < ppl && pt + i < p0 + out_px && pt + i < g.HW) lo_[pt + i] = from_f32<T>(v);
+  for (int u = 0; u < 3; ++u) {
+    const float lft = tid > 0 ? s_ex[u * kBlock + tid - 1] : 0.f;             // (the run's first and last pixel are halo of halo: never read below)
+    const float rgt = tid < kBlock - 1 ? s_ex[(3 + u) * kBlock + tid + 1] : 0.f;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float tl = i > 0 ? t[u * 3][i > 0 ? i - 1 : 0] : lft;
+      const float tr = i < PPT - 1 ? t[u * 3 + 2][i < PPT - 1 ? i + 1 : 0] : rgt;
+      h[u][i] = ml[i] * tl + t[u * 3 + 1][i] + mr[i] * tr;
     }
+  }
+  // vertical step: rows y-1 and y+1 through LDS
+  store_vec<float, PPT>(s_h + tid * PPT, h[0]);
+  store_vec<float, PPT>(s_h + SLOTS + tid * PPT, h[2]);
+  __syncthreads();
+  const float bias = A.p.bh[0];
+  T* lg = static_cast<T*>(A.logits) + static_cast<size_t>(b) * g.HW;
+  float o[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = tid * PPT + i;
+    const bool out = s0 + i >= p0 && s0 + i < pend;             // (then k - W >= 1 and k + W <= SLOTS - 2)
+    o[i] = out ? (s_h[k - g.W] + h[1][i] + s_h[SLOTS + k + g.W]) + bias : 0.f;
+  }
+  if (VEC == 4 && PPT > 1) {                                    // p0, pend, s0 are multiples of PPT: a thread's group is wholly an output or not
+    if (s0 >= p0 && s0 < pend) store_vec<T, PPT>(lg + s0, o);
+  } else {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i)
+      if (s0 + i >= p0 && s0 + i < pend) lg[s0 + i] = from_f32<T>(o[i]);
   }
 #ifdef MGACBAM_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -670,11 +681,16 @@ __device__ __forceinline__ void head_out_body(const HeadArgs& A, const int wg, f
 }
 
 template <typename T, int VEC>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_head_out(const Group<HeadArgs> G) {
-  extern __shared__ __align__(16) float smem[];
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void k_head_out(const Group<HeadArgs> G) {
+  __shared__ __align__(16) float s_par[kHeadOutParCh * 12];
+  __shared__ __align__(16) float s_ex[6 * kBlock];
+  __shared__ __align__(16) float s_h[2 * 4 * kBlock];
   int local;
   const int l = find_level(G, blockIdx.x, local);
-  head_out_body<T, VEC>(G.lv[l], local, smem);
+  const HeadArgs& A = G.lv[l];
+  if (A.out_ppt == 4) head_out_run<T, VEC, 4>(A, local, s_par, s_ex, s_h);
+  else if (A.out_ppt == 2) head_out_run<T, VEC, 2>(A, local, s_par, s_ex, s_h);
+  else head_out_run<T, VEC, 1>(A, local, s_par, s_ex, s_h);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

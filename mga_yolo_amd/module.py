@@ -272,7 +272,7 @@ def _eca_host_forward(x, mask, w, beta, cfg: EcaConfig) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------------------
 # MGAMaskHead: mirror of mga_yolo/nn/modules/segmentation.py:34-127
 # ---------------------------------------------------------------------------------------------------------
-_HEAD_MAX_W = 1390   # widest image row the mask-head kernels stage in LDS (csrc/head.cuh: head_out_shape); wider features run torch ops
+_HEAD_MAX_W = 500    # widest image row the mask-head 3x3 kernels hold in one pixel run (csrc/head.cuh: head_out_shape); wider features run torch ops
 
 
 class _HeadCfg:
