@@ -10,10 +10,13 @@ static int head_check_shape(int B, int C, int H, int W, int hidden) {
     return fail(MGACBAM_E_SHAPE, "mask head: bad shape B=%d C=%d H=%d W=%d hidden=%d", B, C, H, W, hidden);
   if (static_cast<long long>(H) * W > (1ll << 28) || static_cast<long long>(B) * std::max(C, hidden) * H * W > (1ll << 40))
     return fail(MGACBAM_E_SHAPE, "mask head: tensor too large B=%d C=%d H=%d W=%d", B, C, H, W);
-  // the 3x3 kernels stage runs of pixels with a halo of W+1 either side in LDS: rows wider than the budget are refused here, not at launch
+  // the 3x3 kernels work on runs of pixels with a halo of W+1 either side (k_head_out: inside a run of at most 1024 pixels; k_head_bwd_act:
+  // an LDS plane of run + halo): rows wider than that are refused here, not at launch; one sample's z block must fit a buffer descriptor
   { int ppt, opx, per;
-    if (!head_out_shape(hidden, H * W, W, ppt, opx, per) || (static_cast<size_t>(kBlock) * 4 + 2 * (static_cast<size_t>(W) + 1) + 16 * kHeadJC * kHeadNStat) * sizeof(float) > 60 * 1024)
-      return fail(MGACBAM_E_SHAPE, "mask head: image rows of W=%d do not fit the 3x3 kernels' pixel runs (W <= 500)", W); }
+    if (!head_out_shape(hidden, H * W, W, ppt, opx, per) || W > 500)
+      return fail(MGACBAM_E_SHAPE, "mask head: image rows of W=%d do not fit the 3x3 kernels' pixel runs (W <= 500)", W);
+    if (static_cast<long long>(hidden) * H * W >= (1ll << 30))
+      return fail(MGACBAM_E_SHAPE, "mask head: hidden * H * W = %lld does not fit a buffer descriptor (< 2^30)", static_cast<long long>(hidden) * H * W); }
   return 0;
 }
 struct HeadTiling { int vec, hidp, cp, tile_px, tps, nwg, gx_tile_px, gx_tps, fw_kw, gx_kw, fw_mtw, gx_mtw, nwg_out, out_ppt, out_px, out_per, nwg1, act_ppt, act_hl, ncb, nshare, gw2; };

@@ -681,7 +681,7 @@ __device__ __forceinline__ void head_out_run(const HeadArgs& A, const int wg, fl
 }
 
 template <typename T, int VEC>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void k_head_out(const Group<HeadArgs> G) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void k_head_out(const Group<HeadArgs> G) {
   __shared__ __align__(16) float s_par[kHeadOutParCh * 12];
   __shared__ __align__(16) float s_ex[6 * kBlock];
   __shared__ __align__(16) float s_h[2 * 4 * kBlock];
