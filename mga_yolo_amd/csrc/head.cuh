@@ -558,12 +558,12 @@ __device__ __forceinline__ void head_out_run(const HeadArgs& A, const int wg, fl
 #pragma unroll
     for (int jj = 0; jj < CB; ++jj) {
       const unsigned ro = static_cast<unsigned>(min(c0 + jj, g.hid - 1)) * row_bytes;   // past the last channel: a valid row, weight 0 below
-      if (VEC == 4 && PPT == 4) {
+      if constexpr (VEC == 4 && PPT == 4) {
         const v4f32 f = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(zrs, so[0], ro, 0));   // (whole-vector cast: see bwd.cuh load_plane_agent)
         zv[jj][0] = f.x; zv[jj][1] = f.y; zv[jj][2] = f.z; zv[jj][3] = f.w;
-      } else if (VEC == 4 && PPT == 2) {
+      } else if constexpr (VEC == 4 && PPT == 2) {
         const v2f32 f = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(zrs, so[0], ro, 0));
-        zv[jj][0] = f.x; zv[jj][PPT - 1] = f.y;
+        zv[jj][0] = f.x; zv[jj][1] = f.y;
       } else {
 #pragma unroll
         for (int i = 0; i < PPT; ++i) zv[jj][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrs, so[i], ro, 0));
