@@ -565,13 +565,17 @@ __global__ __launch_bounds__(kBlock) BWD_OCC void k_bwd_r12(const R12Group R) {
     if (i < R.g.n && bid >= R.seg[p][i]) l = i;
   const int local = bid - R.seg[p][l];
   const BwdArgs& A = R.g.lv[l];
-  if (p == 0) { bwd_reduce1_body<T, VEC, true>(A, local, smem); return; }
-  if (p == 1) { if (local < A.nconv) bwd_convT_body<7, true>(A, local, smem); return; }
-  if (p == 2) { if (local < A.nwsa) bwd_wsa_body<7, false, true>(A, local, smem); return; }
-  TRACE_MARK(A.trace, blockIdx.x, 0);
-  bwd_reduce2_body<T, VEC, CPT, true>(A, local, smem);
+#ifdef MGACBAM_TRACE
+  TRACE_MARK(A.trace, blockIdx.x, 0);                           // tools/trace_r12.py: start, phase (slot 14), end
+  if (A.trace && threadIdx.x == 0) A.trace[static_cast<size_t>(blockIdx.x) * 16 + 14] = p + 1;
+#endif
+  if (p == 0) bwd_reduce1_body<T, VEC, true>(A, local, smem);
+  else if (p == 1) { if (local < A.nconv) bwd_convT_body<7, true>(A, local, smem); }
+  else if (p == 2) { if (local < A.nwsa) bwd_wsa_body<7, false, true>(A, local, smem); }
+  else bwd_reduce2_body<T, VEC, CPT, true>(A, local, smem);
 #ifdef MGACBAM_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   TRACE_MARK(A.trace, blockIdx.x, 10);
 #endif
 }

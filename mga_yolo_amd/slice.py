@@ -7,7 +7,7 @@
     feeds both), accumulated in the head's GEMM epilogue instead of a feature-sized add.
 
 Everything between the neck's P3/P4/P5 features and the Detect head's inputs -- i.e. every MGA-specific layer of the reference model
-plus its loss terms -- runs as C-ABI calls on pre-allocated buffers: 4 + 2 + 2 launches forward, 1 + 3 + 5 backward for
+plus its loss terms -- runs as C-ABI calls on pre-allocated buffers: 3 + 2 + 2 launches forward, 1 + 2 + 5 backward for
 all three levels together, recorded into one hipGraph.  The backbone / neck / Detect / detection loss are out of scope:
 their contribution enters as given tensors -- `gy_l` (dL/d refined_l, what Detect's backward would deliver) and `det_loss`
 (the criterion's 3-vector).
@@ -146,5 +146,5 @@ class SlicePlan:
         return self.shapes[0][0]
 
     def launches(self) -> dict:
-        return dict(forward="4 (heads) + 2 (MaskCBAM) + 2 (seg loss + Kendall)",
-                    backward="1 (seg loss + Kendall) + 3 (MaskCBAM) + 5 (heads)")
+        return dict(forward="3 (heads) + 2 (MaskCBAM) + 2 (seg loss + Kendall)",
+                    backward="1 (seg loss + Kendall) + 2 (MaskCBAM) + 5 (heads)")
