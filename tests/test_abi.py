@@ -83,6 +83,10 @@ def test_argument_errors_are_reported_not_launched(built_lib):
     lib = _lib.load()
     assert lib.mgacbam_ctx_bytes(0, 64, 8, 8, 4) == 0 and b"bad shape" in lib.mgacbam_last_error()
     assert lib.mgacbam_bwd_scratch_bytes(1, 8, 8, 8, 1, 4) == 0 and b"odd" in lib.mgacbam_last_error()   # even k
+    # mask head: rows wider than a pixel run holds are a shape error from the size queries on (the module runs torch ops for them)
+    assert lib.mgahead_ctx_bytes(1, 8, 2, 500, 8) > 0
+    assert lib.mgahead_ctx_bytes(1, 8, 2, 501, 8) == 0 and b"W <= 500" in lib.mgacbam_last_error()
+    assert lib.mgahead_bwd_scratch_bytes(1, 8, 1 << 14, 1 << 14, 8) == 0        # hidden * H * W beyond a buffer descriptor
     lv = (_lib.FwdLevel * 1)()
     assert lib.mgacbam_forward(lv, 1, None) == -1            # MGACBAM_E_NULL: x / y / ctx missing
     assert lib.mgacbam_forward(lv, 0, None) == -5            # MGACBAM_E_LEVELS

@@ -180,6 +180,34 @@ def test_device_full_size_checksums_vs_reference(built_lib, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,C,hid,H,W", [(2, 16, 64, 3, 100),     # hidden > 32 takes 1 pixel per thread; a run of 256 cannot hold W + 1 either side: 2
+                                         (1, 8, 8, 2, 333),       # H*W % 4 != 0: the scalar-access form, 4 pixels per thread
+                                         (1, 8, 40, 1, 500),      # the widest row k_head_out takes: 16 outputs per run of 1024
+                                         (1, 16, 200, 5, 36)])    # more hidden channels than one LDS chunk of constants (128)
+def test_device_wide_rows_vs_live_oracle(built_lib, B, C, hid, H, W):
+    """k_head_out holds a pixel run and W + 1 pixels either side in 256 x {1, 2, 4} staged pixels: rows that force the larger forms, the
+    4-byte access form and the widest row, against the oracle evaluated live (fp32, 1e-4 as for the goldens)."""
+    from mga_yolo_amd import MGAMaskHead
+    torch.manual_seed(11)
+    m = MGAMaskHead(C, hid).train()
+    g = torch.Generator().manual_seed(13)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.add_(0.3 * torch.randn(p_.shape, generator=g))
+    x = torch.randn(B, C, H, W, generator=g)
+    gl = torch.randn(B, 1, H, W, generator=g)
+    p = HO.HeadParams.from_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+    lo, c = HO.forward(x, p, True)
+    go = HO.backward(gl, x, p, c, True)
+    m.cuda()
+    xd = x.cuda().requires_grad_(True)
+    y = m(xd)
+    y.backward(gl.cuda())
+    assert rel_err(y, lo) < TOL and rel_err(xd.grad, go["gx"]) < TOL
+    assert rel_err(m.head.weight.grad, go["gwh"]) < TOL and rel_err(m.proj[0].weight.grad.reshape(hid, C), go["gw1"]) < TOL
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
 def test_device_half_precision_io(built_lib, dtype, tol):
     """fp16 / bf16 features and logits with fp32 accumulation and fp32 parameters, against the fp32 oracle on the rounded inputs."""
