@@ -412,7 +412,9 @@ def main():
     fence()
     gc.collect()
     gc.disable()                 # a collector pause inside a 4-40 ms timed region is host noise, not the path being measured
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()                 # extra key only (ms_per_step_device): the same K steps by the device's clock, without the host's wake-up at both ends
     if world == 1 and not args.no_graph and args.steps_per_graph > 1:     # diagnostic: exactly K steps, U per replay + the remainder
         for _ in range(args.steps // U):
             g_multi.replay()
@@ -422,8 +424,10 @@ def main():
         for _ in range(args.steps):
             step()
     exchange.finish()            # the last step's exchange is inside the timed region
+    ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
+    ms_device = ev0.elapsed_time(ev1) / args.steps
     gc.enable()
     plan.check_handoff()         # raises if any in-launch hand-off of the run timed out (the step would have been wrong AND slow)
     if world > 1:
@@ -498,7 +502,7 @@ def main():
 
     if rank == 0:
         line = dict(metric="images/s (MaskCBAM fwd+bwd step at P3/P4/P5, YOLOv8n 640x640)", value=round(value, 1), unit="images/s",
-                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
+                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4), ms_per_step_device=round(ms_device, 4),
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                     config=dict(workload=desc, batch_per_gpu=batch, global_batch=batch * world,
                                 levels=[list(s) for s in plan.shapes], parallelism=f"dp{world}", backend=(args.backend if world > 1 else None),
