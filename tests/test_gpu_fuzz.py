@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("script,n", [("fuzz_parity.py", 100),      # MaskCBAM / MaskECA: every launch-geometry branch, mask kinds, conv sizes
                                       ("fuzz_head.py", 60),         # MGAMaskHead: channel / hidden widths off the MFMA tile sizes, odd H*W, wide rows, half I/O
                                       ("fuzz_pyramid.py", 25),      # grouped pyramid calls vs per-level calls
-                                      ("fuzz_rows.py", 25)])        # x-resident forward / folded backward row hand-offs
+                                      ("fuzz_rows.py", 25)])        # segmentation loss (both modes, resized targets) and the ProbMaskGater launch
 def test_fuzzer_slice_is_clean(built_lib, script, n):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", script), str(n), "11"], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, PYTHONPATH=ROOT))
