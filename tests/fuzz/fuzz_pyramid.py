@@ -12,10 +12,61 @@ from mga_yolo_amd import functional as F
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+only = {int(a.split("=", 1)[1]) for a in sys.argv if a.startswith("--only=")}       # re-run single calls of a campaign (same random stream)
+repeat = max([int(a.split("=", 1)[1]) for a in sys.argv if a.startswith("--repeat=")] + [1])
 bad = 0
+ties = 0
+
+
+def run_call(it, spec):
+    global bad
+    lv, ref = [], []
+    for l, (B, C, H, W, k, kind, dt, mask_grad) in enumerate(spec):
+        x, mask, gy = synth(B, C, H, W, seed=7000 + 10 * it + l, mask_kind=kind)
+        x, gy = x.to(dt).float(), gy.to(dt).float()
+        p = O.Params.default_init(C, k=k, seed=it + l)
+        y_o, c = O.forward(x, mask, p)
+        g_o = O.backward(gy, x, mask, p, O.Config(), c)
+        xd = x.cuda().to(dt).requires_grad_(True)
+        md = None if mask is None else mask.cuda().requires_grad_(mask_grad)
+        ps = [t.cuda().requires_grad_(True) for t in (p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta)]
+        lv.append((xd, md, ps, F.BlockConfig(hidden=p.w1.shape[0], k=k)))
+        # a channel arg-max decided by less than the last bits of ca (x_c ca_c of the two best channels within 2e-6 relative): the oracle's
+        # and the device's ca differ by ~1e-7, so the routed sub-gradient may go to either channel -- y agrees, gx differs at that pixel
+        u2 = (x * c.ca.reshape(B, C, 1, 1)).topk(min(2, C), dim=1).values
+        tie = C > 1 and bool(((u2[:, 0] - u2[:, 1]) <= 2e-6 * u2[:, 0].abs()).any())
+        ref.append((y_o, g_o, gy, dt, (B, C, H, W, k, kind), tie))
+    try:
+        ys = F.mask_cbam_pyramid(lv)
+        torch.autograd.backward(list(ys), [r[2].cuda().to(r[3]) for r in ref])
+        for l, ((xd, md, ps, _), (y_o, g_o, gy, dt, desc, tie)) in enumerate(zip(lv, ref)):
+            tol = {torch.float32: 1e-4, torch.float16: 4e-3, torch.bfloat16: 3e-2}[dt]
+            floor = 1e-7 * float(gy.norm() * xd.detach().float().norm().cpu())   # absolute: fp32 rounding of a cancelling sum's terms
+            checks = dict(y=(ys[l].float(), y_o), gx=(xd.grad.float(), g_o["gx"]), gw1=(ps[0].grad, g_o["gw1"]), gwsa=(ps[4].grad, g_o["gwsa"]),
+                          gbeta=(ps[5].grad, g_o["gbeta"]), gw2=(ps[2].grad, g_o["gw2"]))
+            if md is not None and md.requires_grad:
+                checks["gmask"] = (md.grad, g_o["gmask"])
+            if tie:
+                global ties
+                ties += 1
+                checks = dict(y=checks["y"])                            # the forward does not depend on which of two equal channels won
+            for name, (got, want) in checks.items():
+                d = (got.detach().double().cpu() - want.double()).abs()
+                dv = float(d.max())
+                bar = tol * float(want.double().abs().max()) + (floor if name not in ("y", "gx") else 0.0)
+                if not dv <= max(bar, 1e-30):
+                    bad += 1
+                    where = [int(v) for v in torch.unravel_index(d.argmax(), d.shape)]
+                    print(f"FAIL call {it} level {l} {desc} {dt}: {name} |diff| {dv:.2e} > {bar:.2e} at {where}, {int((d > bar).sum())} elements over the bar",
+                          flush=True)
+    except Exception as ex:   # noqa: BLE001
+        bad += 1
+        print(f"ERROR call {it}: {[r[4] for r in ref]}: {type(ex).__name__}: {ex}", flush=True)
+
+
 for it in range(n):
     nl = rng.randint(2, 5)
-    lv, ref = [], []
+    spec = []
     for l in range(nl):
         B = rng.choice([1, 2, 4, 8, 11])
         C = rng.choice([8, 16, 64, 128, 192, 256])
@@ -23,34 +74,13 @@ for it in range(n):
         k = rng.choice([7, 7, 3, 5, 9])
         kind = rng.choice(["randn", "sparse", "none", "mixed"]) if B > 1 else rng.choice(["randn", "none"])
         dt = rng.choice([torch.float32, torch.float32, torch.float16, torch.bfloat16])
-        x, mask, gy = synth(B, C, H, W, seed=7000 + 10 * it + l, mask_kind=kind)
-        x, gy = x.to(dt).float(), gy.to(dt).float()
-        p = O.Params.default_init(C, k=k, seed=it + l)
-        y_o, c = O.forward(x, mask, p)
-        g_o = O.backward(gy, x, mask, p, O.Config(), c)
-        xd = x.cuda().to(dt).requires_grad_(True)
-        md = None if mask is None else mask.cuda().requires_grad_(rng.random() < 0.8)
-        ps = [t.cuda().requires_grad_(True) for t in (p.w1, p.b1, p.w2, p.b2, p.wsa, p.beta)]
-        lv.append((xd, md, ps, F.BlockConfig(hidden=p.w1.shape[0], k=k)))
-        ref.append((y_o, g_o, gy, dt, (B, C, H, W, k, kind)))
-    try:
-        ys = F.mask_cbam_pyramid(lv)
-        torch.autograd.backward(list(ys), [r[2].cuda().to(r[3]) for r in ref])
-        for l, ((xd, md, ps, _), (y_o, g_o, gy, dt, desc)) in enumerate(zip(lv, ref)):
-            tol = {torch.float32: 1e-4, torch.float16: 4e-3, torch.bfloat16: 3e-2}[dt]
-            floor = 1e-7 * float(gy.norm() * xd.detach().float().norm().cpu())   # absolute: fp32 rounding of a cancelling sum's terms
-            checks = dict(y=(ys[l].float(), y_o), gx=(xd.grad.float(), g_o["gx"]), gw1=(ps[0].grad, g_o["gw1"]), gwsa=(ps[4].grad, g_o["gwsa"]),
-                          gbeta=(ps[5].grad, g_o["gbeta"]), gw2=(ps[2].grad, g_o["gw2"]))
-            if md is not None and md.requires_grad:
-                checks["gmask"] = (md.grad, g_o["gmask"])
-            for name, (got, want) in checks.items():
-                dv = float((got.detach().double().cpu() - want.double()).abs().max())
-                bar = tol * float(want.double().abs().max()) + (floor if name not in ("y", "gx") else 0.0)
-                if not dv <= max(bar, 1e-30):
-                    bad += 1
-                    print(f"FAIL call {it} level {l} {desc} {dt}: {name} |diff| {dv:.2e} > {bar:.2e}", flush=True)
-    except Exception as ex:   # noqa: BLE001
-        bad += 1
-        print(f"ERROR call {it}: {[r[4] for r in ref]}: {type(ex).__name__}: {ex}", flush=True)
-print(f"pyramid fuzz: {n} calls, {bad} failures")
+        mask_grad = rng.random() < 0.8 if kind != "none" else False              # (drawn only when the level has a mask)
+        spec.append((B, C, H, W, k, kind, dt, mask_grad))
+    if only and it not in only:
+        continue
+    for _ in range(repeat):
+        run_call(it, spec)
+    if only:
+        print(f"call {it}: {[(s_[:6], str(s_[6]).replace('torch.', ''), s_[7]) for s_ in spec]}", flush=True)
+print(f"pyramid fuzz: {n} calls, {bad} failures ({ties} levels with a channel arg-max near-tie: forward only)")
 sys.exit(1 if bad else 0)
