@@ -26,7 +26,10 @@ _INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
 # -fno-slp-vectorize: clang's SLP vectoriser turns the kernels' per-pixel FMA chains into v_pk_fma_f32 whose scalar operands then need
 # v_mov / lane spills (k_head_bwd_act: 342 v_mov + 275 spills).  Without it -- five interleaved A/B pairs on one MI355X -- the
 # MaskCBAM step is 1.7 % faster (0.2010 -> 0.1976 ms) and the layer-loop slice 1.6 % (0.3989 -> 0.3926); on the mask-head unit alone: 0.4 %.
-BASE_FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wno-pass-failed", "-fno-slp-vectorize"]
+# -O2 rather than -O3: the MaskCBAM step is the same (0.1997 / 0.1995 ms), the layer-loop slice 1.9 % faster (0.3941 -> 0.3867 ms, four pairs): the
+# mask-head and loss kernels lose what -O3's extra unrolling / hoisting cost them in registers.  (Measured and not adopted: the scheduler
+# strategies max-ilp (k_gate +3 us), iterative-minreg (+6 %), max-memory-clause (same); -fno-vectorize (same).)
+BASE_FLAGS = ["-O2", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wno-pass-failed", "-fno-slp-vectorize"]
 UNIT_FLAGS: dict = {}          # extra flags per translation unit (none at present)
 
 
