@@ -60,7 +60,7 @@ static HeadTiling head_tiling(int B, int C, int H, int W, int hidden) {
   if (t.gw2) {
     const long long chunks64 = static_cast<long long>(B) * ((HW + kHeadGwPx - 1) / kHeadGwPx);
     const long long cap = std::max(1ll, std::min(512ll, (4ll << 20) / per_share));
-    t.nshare = static_cast<int>(std::max(1ll, std::min(cap, chunks64 / 4)));   // (measured: 2-4 chunks per workgroup and 512-2048 shares all within 1 %; 6+ chunks, one resident round: +12 %)
+    t.nshare = static_cast<int>(std::max(1ll, std::min(cap, chunks64 / std::max(1, knobs().head_gw_div))));   // (measured: 2-4 chunks per workgroup and 512-2048 shares all within 1 %; 6+ chunks, one resident round: +12 %)
   }
   return t;
 }

@@ -116,6 +116,8 @@ static int env_int(const char* name, int dflt) {
 // Tuning / test knobs come from the environment ONCE (first call) -- not per call: the eager path makes ~50 look-ups per step
 // otherwise.  mgacbam_reload_env() re-reads them (tests and tuning sweeps that change the environment in-process).
 struct Knobs {
+  int head_gw_div;         // MGAHEAD_GW_DIV (default 5): 64-pixel chunks per k_head_bwd_gw2 workgroup (pixel shares = chunks / this).  5: the YOLOv8n pyramid's 1,008
+                           // workgroups are one resident round at the kernel's 108 VGPRs (4 per CU): slice 0.3886 -> 0.3852 ms; 3, 6, 8 and config 3: no difference
   int bwd_merge;           // MGACBAM_BWD_MERGE (default 1): k_bwd_reduce1 + conv + dWsa tiles + k_bwd_reduce2 as one launch (k_bwd_r12)
   int wsa_tail;            // MGACBAM_WSA_TAIL (default 0, opt-in): dWsa tile partials + sums as the last workgroups of the k_bwd_apply launch
   int gate_narrow;         // MGACBAM_GATE_NARROW (default 0): k_gate also for tiles narrower than an image row
@@ -128,6 +130,7 @@ struct Knobs {
 static Knobs read_knobs() {
   Knobs k;
   k.bwd_merge = env_int("MGACBAM_BWD_MERGE", 1);
+  k.head_gw_div = env_int("MGAHEAD_GW_DIV", 5);
   k.wsa_tail = env_int("MGACBAM_WSA_TAIL", 0);
   k.gate_narrow = env_int("MGACBAM_GATE_NARROW", 0);
   k.gate = env_int("MGACBAM_GATE", 1); k.chan_mintx = env_int("MGACBAM_CHAN_MINTX", 16);
